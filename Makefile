@@ -1,0 +1,56 @@
+# Build of the MI355X-native MinimalOptiX render path.
+#   make            -> device layer (HIP, gfx950), host library + CLI, oracle, hostsim
+#   make device     -> minimaloptix_amd/lib/libmoptix.so        (hipcc --offload-arch=gfx950)
+#   make host       -> minimaloptix_amd/lib/libmoptix_host.so, minimaloptix_amd/lib/moptix_render
+#   make oracle     -> oracle/liboracle.so                      (test infrastructure)
+#   make hostsim    -> tests/hostsim/libhostsim.so              (test infrastructure)
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+ARCH     ?= gfx950
+LIBDIR   := minimaloptix_amd/lib
+CSRC     := minimaloptix_amd/csrc
+HOST     := minimaloptix_amd/host
+
+# -ffp-contract=off: arithmetic contract AC4; explicit fmaf() where a fused op is specified
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -include cstring
+CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -mavx2 -mfma -Wall -Wno-unused-function -Wno-unknown-pragmas
+
+DEV_SRCS := $(CSRC)/moptix_api.hip $(CSRC)/megakernel.hip $(CSRC)/lbvh.hip
+DEV_OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(DEV_SRCS))
+DEV_HDRS := $(wildcard $(CSRC)/*.h) include/moptix.h
+HOST_SRCS := $(HOST)/obj_loader.cpp $(HOST)/scene_file.cpp $(HOST)/scenes.cpp $(HOST)/standin_scenes.cpp \
+             $(HOST)/image_io.cpp $(HOST)/minimal_optix.cpp $(HOST)/host_capi.cpp
+HOST_OBJS := $(patsubst $(HOST)/%.cpp,build/host_%.o,$(HOST_SRCS))
+HOST_HDRS := $(wildcard $(HOST)/*.h) $(wildcard $(CSRC)/pt_*.h) include/moptix.h include/moptix_host.h
+
+all: device host oracle hostsim
+
+device: $(LIBDIR)/libmoptix.so
+host: $(LIBDIR)/libmoptix_host.so $(LIBDIR)/moptix_render
+oracle:
+	$(MAKE) -C oracle -s
+hostsim:
+	$(MAKE) -C tests/hostsim -s
+
+build/%.o: $(CSRC)/%.hip $(DEV_HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libmoptix.so: $(DEV_OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(DEV_OBJS)
+
+build/host_%.o: $(HOST)/%.cpp $(HOST_HDRS)
+	@mkdir -p build
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+$(LIBDIR)/libmoptix_host.so: $(HOST_OBJS) $(LIBDIR)/libmoptix.so
+	$(CXX) -shared -fPIC -o $@ $(HOST_OBJS) -L$(LIBDIR) -lmoptix -Wl,-rpath,'$$ORIGIN'
+
+$(LIBDIR)/moptix_render: $(HOST)/main.cpp $(LIBDIR)/libmoptix_host.so
+	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/main.cpp -L$(LIBDIR) -lmoptix_host -lmoptix -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+
+clean:
+	rm -rf build $(LIBDIR)/*.so $(LIBDIR)/moptix_render oracle/liboracle.so tests/hostsim/libhostsim.so
+
+.PHONY: all device host oracle hostsim clean

@@ -1,0 +1,204 @@
+/*
+ * moptix.h -- C ABI of the MI355X-native device layer that replaces the OptiX 5
+ * host API + rtTrace/acceleration + .cu programs on the MinimalOptiX render path.
+ *
+ * The reference has no FFI of its own: the path sits behind the OptiX C++ host
+ * API (optixpp) as called by class MinimalOptiX.  Each entry point below names
+ * the reference call site(s) it replaces (paths relative to
+ * /root/reference/MinimalOptiX/).  Plain pointers and sizes only; host memory
+ * passed in is copied (as OptiX does on setUserData/map+memcpy); no exceptions
+ * cross this boundary -- every function returns MOPTIX_OK (0) or a negative
+ * error code and moptix_last_error() gives the text.
+ *
+ * Built as minimaloptix_amd/lib/libmoptix.so (hipcc --offload-arch=gfx950).
+ * There is NO CPU fallback behind this ABI: without a gfx950 device every
+ * compute entry point fails with MOPTIX_ERR_NO_DEVICE.
+ */
+#ifndef MOPTIX_H
+#define MOPTIX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOPTIX_OK                 0
+#define MOPTIX_ERR_INVALID       -1   /* bad argument / bad handle                 */
+#define MOPTIX_ERR_NO_DEVICE     -2   /* no HIP device / not gfx950                 */
+#define MOPTIX_ERR_HIP           -3   /* HIP runtime error (text in last_error)     */
+#define MOPTIX_ERR_STATE         -4   /* call order (e.g. launch before build_accel)*/
+#define MOPTIX_ERR_LIMIT         -5   /* scene exceeds a compiled limit             */
+
+typedef struct moptix_context_t* moptix_context;
+
+/* ---- records crossing host<->device (Structures.h) ----------------------- */
+typedef struct moptix_float3 { float x, y, z; } moptix_float3;
+typedef struct moptix_float4 { float x, y, z, w; } moptix_float4;
+
+/* Structures.h:12-20 CamParams */
+typedef struct moptix_cam_params {
+  moptix_float3 origin, horizontal, vertical, scrLowerLeftCorner, u, v;
+  float lensRadius;
+} moptix_cam_params;
+
+/* Structures.h:22-26 SphereParams (velocity is host-side animation state, unused on device) */
+typedef struct moptix_sphere_params { float radius; moptix_float3 center; moptix_float3 velocity; } moptix_sphere_params;
+
+/* Structures.h:28-33 QuadParams, as produced by setQuadParams (utils_host.cpp:67-75).
+ * Unpadded here; the reference's float4 alignment padding is not part of the ABI. */
+typedef struct moptix_quad_params { moptix_float4 plane; moptix_float3 v1, v2, anchor; } moptix_quad_params;
+
+/* which closest-hit program the material carries (Material.cu:28,49,72,118,238) */
+enum { MOPTIX_MAT_LAMBERTIAN = 0, MOPTIX_MAT_METAL = 1, MOPTIX_MAT_GLASS = 2, MOPTIX_MAT_DISNEY = 3, MOPTIX_MAT_LIGHT = 4 };
+enum { MOPTIX_BRDF_NORMAL = 0, MOPTIX_BRDF_GLASS = 1 };   /* Structures.h:49 BrdfType   */
+enum { MOPTIX_LIGHT_SPHERE = 0, MOPTIX_LIGHT_QUAD = 1 };  /* Structures.h:68 LightShape */
+
+/* Structures.h:51-66 DisneyParams */
+typedef struct moptix_disney_params {
+  int32_t albedoID;              /* 0 = RT_TEXTURE_ID_NULL; textures: SURVEY 8(f) "next" */
+  moptix_float3 color, emission;
+  float metallic, subsurface, specular, roughness, specularTint, anisotropic;
+  float sheen, sheenTint, clearcoat, clearcoatGloss;
+  int32_t brdfType;
+} moptix_disney_params;
+
+/* Structures.h:70-80 LightParams */
+typedef struct moptix_light_params {
+  moptix_float3 position, normal, emission, u, v;
+  float area, radius;
+  int32_t shape;
+} moptix_light_params;
+
+/* One material = createMaterial + setClosestHitProgram(0, kind) [+ setAnyHitProgram(1,
+ * disneyAnyHit) for MOPTIX_MAT_DISNEY] + setUserData of the matching params
+ * (Structures.h:35-47 Lambertian/Metal/Glass, :51 Disney, :70 Light.emission). */
+typedef struct moptix_material {
+  int32_t kind;
+  moptix_float3 albedo;          /* LambertianParams / MetalParams / GlassParams .albedo */
+  float fuzz;                    /* MetalParams.fuzz   */
+  float refIdx;                  /* GlassParams.refIdx */
+  moptix_float3 emission;        /* light material: LightParams.emission */
+  moptix_disney_params disney;   /* MOPTIX_MAT_DISNEY */
+} moptix_material;
+
+/* Context variables (MinimalOptiX.cpp:136-151), miss bgColor (:165...), raygen
+ * camParams (:256...) and the launch size (:546). */
+typedef struct moptix_params {
+  uint32_t width, height;        /* fixedWidth/fixedHeight, MinimalOptiX.h:82-83 */
+  uint32_t rayMaxDepth;          /* 256   MinimalOptiX.h:85 */
+  float rayMinIntensity;         /* 0.001 MinimalOptiX.h:88 */
+  float rayEpsilonT;             /* 0.001 MinimalOptiX.h:89 */
+  moptix_float3 bgColor;         /* staticMiss bgColor, miss.cu:7 */
+  moptix_cam_params cam;
+} moptix_params;
+
+/* Counters of a counting launch (moptix_render_counted): the algorithmic-byte
+ * model of SURVEY 8(d) is evaluated from these. */
+typedef struct moptix_stats {
+  uint64_t samples;              /* camera samples traced                                 */
+  uint64_t primaryRays, bounceRays, shadowRays;
+  uint64_t nodeFetches;          /* 64-byte two-child BVH nodes fetched                   */
+  uint64_t triTests;             /* 48-byte triangle records tested                       */
+  uint64_t closestHits;          /* closest-hit shading fetches                           */
+  uint64_t lightLoads;           /* LightParams records read for NEE                      */
+  uint64_t analyticTests;        /* sphere/quad records tested (brute-force lists)        */
+  uint64_t traversalSteps;       /* wave-level loop iterations (x64 lanes = lane slots)   */
+  uint64_t activeLaneSteps;      /* lanes doing useful work summed over those iterations  */
+} moptix_stats;
+
+typedef struct moptix_accel_info {
+  uint32_t nTriangles, nNodes, maxLeafSize, treeDepth;
+  float buildMs;                 /* device time of the last LBVH build (HIP events) */
+  uint64_t nodeBytes, triBytes;
+} moptix_accel_info;
+
+/* ---- lifecycle: Context::create()/setRayTypeCount/setEntryPointCount/setStackSize
+ *      (MinimalOptiX.cpp:131-134) --------------------------------------------- */
+int moptix_create(moptix_context* out, int device);
+int moptix_destroy(moptix_context ctx);
+const char* moptix_last_error(moptix_context ctx);           /* ctx may be NULL: last global error */
+const char* moptix_version(void);
+/* run every launch on this hipStream_t (default: a stream the context owns) */
+int moptix_set_stream(moptix_context ctx, void* hipStream);
+
+/* ---- parameters: context[...]->set* (MinimalOptiX.cpp:136-151,165,256) ---- */
+int moptix_set_params(moptix_context ctx, const moptix_params* p);
+
+/* ---- scene upload (MinimalOptiX.cpp:168-249, 362-537, 780-843) ------------ */
+int moptix_clear_scene(moptix_context ctx);
+int moptix_add_material(moptix_context ctx, const moptix_material* m, int32_t* outMatId);
+/* createGeometry+sphereIntersect/sphereBBox+createGeometryInstance (MinimalOptiX.cpp:177-208,796-843) */
+int moptix_add_spheres(moptix_context ctx, const moptix_sphere_params* s, const int32_t* matIds, int32_t n);
+/* ...quadIntersect/quadBBox (MinimalOptiX.cpp:210-240, 505-510, 780-794) */
+int moptix_add_quads(moptix_context ctx, const moptix_quad_params* q, const int32_t* matIds, int32_t n);
+/* one tinyobj shape = one Geometry with six buffers (MinimalOptiX.cpp:392-441, Geometry.cu:114-119).
+ * normals/texcoords may be NULL (count 0); nIdx/tIdx may be NULL or hold -1. */
+int moptix_add_mesh(moptix_context ctx,
+                    const float* positions, int32_t nVerts,
+                    const float* normals, int32_t nNormals,
+                    const float* texcoords, int32_t nTexcoords,
+                    const int32_t* vIdx, const int32_t* nIdx, const int32_t* tIdx, int32_t nFaces,
+                    int32_t matId);
+/* context["lights"] buffer of LightParams (MinimalOptiX.cpp:523-531) */
+int moptix_set_lights(moptix_context ctx, const moptix_light_params* lights, int32_t n);
+/* rewrite sphere i..i+n (updateVideo, MinimalOptiX.cpp:763-764) */
+int moptix_update_spheres(moptix_context ctx, int32_t first, const moptix_sphere_params* s, int32_t n);
+
+/* setAcceleration("NoAccel" | "Trbvh") (MinimalOptiX.cpp:248,378,494,534,748).
+ * "Trbvh" -> Morton-code LBVH built on the device over all triangles; analytic
+ * primitives always stay in brute-force lists. "NoAccel" with triangles present
+ * is rejected (MOPTIX_ERR_INVALID). */
+int moptix_build_accel(moptix_context ctx, const char* kind);
+int moptix_get_accel_info(moptix_context ctx, moptix_accel_info* out);
+/* context->validate() (MinimalOptiX.cpp:542) */
+int moptix_validate(moptix_context ctx);
+
+/* ---- launch --------------------------------------------------------------- */
+/* context["randSeed"]->setInt(seed); context->launch(0,W,H)  (MinimalOptiX.cpp:545-546,774-775):
+ * one sample per pixel, accuBuffer += clamp(color,0,1); blocking. */
+int moptix_launch(moptix_context ctx, int32_t randSeed);
+/* the same nSeeds launches fused into ONE kernel (per pixel the samples are still
+ * added in seed order, so the result is bit-identical to nSeeds moptix_launch calls). */
+int moptix_render(moptix_context ctx, const int32_t* seeds, int32_t nSeeds);
+/* non-blocking variant for stream overlap; moptix_sync() waits. */
+int moptix_render_async(moptix_context ctx, const int32_t* seeds, int32_t nSeeds);
+int moptix_sync(moptix_context ctx);
+/* same work with the in-kernel counters enabled (slower; not for timing) */
+int moptix_render_counted(moptix_context ctx, const int32_t* seeds, int32_t nSeeds, moptix_stats* out);
+
+/* Multi-GPU tile split (new): this context renders only the 8x8-pixel
+ * tiles t (raster order) with t % nRanks == rank.  Default (0,1) = whole frame. */
+int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
+
+/* tuning knobs: "exit_threshold" (lanes), "leaf_size" (1..8, before build_accel),
+ * "blocks_per_cu", "kernel_variant".  Unknown names -> MOPTIX_ERR_INVALID. */
+int moptix_set_option(moptix_context ctx, const char* name, int32_t value);
+int moptix_get_option(moptix_context ctx, const char* name, int32_t* value);
+
+/* ---- output buffer: createBuffer(RT_BUFFER_INPUT_OUTPUT, FLOAT3, W, H) + map()/unmap()
+ *      (MinimalOptiX.cpp:144-147, 44-60).  float3 row-major, row 0 = bottom row. -- */
+int moptix_accum_read(moptix_context ctx, float* dstHost);          /* W*H*3 floats */
+int moptix_accum_clear(moptix_context ctx);
+int moptix_accum_device_ptr(moptix_context ctx, void** devPtr);     /* for device-side gather/reduce */
+/* render into caller-owned device memory (e.g. a torch tensor) instead; NULL restores the own buffer */
+int moptix_accum_bind(moptix_context ctx, void* devPtr);
+/* updateContent (MinimalOptiX.cpp:43-66) on the device: out[(H-1-y)*W+x] = u8(clamp(accu/n,0,1)*255),
+ * optionally clearing the accumulator. dstHost: W*H*3 bytes, row 0 = top. */
+int moptix_resolve_rgb8(moptix_context ctx, float nAccumulation, int clearBuffer, uint8_t* dstHost);
+
+/* ---- measurement ----------------------------------------------------------- */
+/* device time (HIP events on the launch stream) of render kernels since the last reset */
+int moptix_kernel_time(moptix_context ctx, double* totalMs, uint64_t* nLaunches, int reset);
+
+/* debug/validation: copy the built BVH to host (nodes: nNodes*64 B, tris: nTriangles*48 B,
+ * triPrimIds: nTriangles int32 = original face index of each record). Any pointer may be NULL. */
+int moptix_debug_read_accel(moptix_context ctx, void* nodes, void* tris, int32_t* triPrimIds);
+/* nearest-hit query for n rays (BVH-vs-brute-force tests): rays = n x {ox,oy,oz,dx,dy,dz,tmin,tmax};
+ * outT[n], outPrim[n] (prim id: spheres, quads, triangles; -1 = miss). */
+int moptix_debug_trace(moptix_context ctx, const float* rays, int32_t n, float* outT, int32_t* outPrim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOPTIX_H */

@@ -1,0 +1,22 @@
+// lbvh.h -- device LBVH builder interface (implementation: lbvh.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pt_types.h"
+
+namespace pt {
+
+struct LbvhResult {
+  Node64* nodes = nullptr;     // device, nNodes
+  Tri48* tris = nullptr;       // device, nTris (sorted / leaf order)
+  TriShade* shade = nullptr;   // device, nTris
+  int nTris = 0, nNodes = 0, rootRef = kEmptyRef, depth = 0, leafSize = 0;
+  float buildMs = 0.f;
+};
+
+// facePos: 9 floats per face (p0 p1 p2) in upload order; faceNrm: 9 per face; device pointers.
+// Allocates the result arrays with hipMalloc (caller frees with lbvh_free).
+hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dFaceNrm, const int* dFaceHasNrm,
+                      const int* dFaceMat, int nFaces, int leafSize, LbvhResult* out);
+void lbvh_free(LbvhResult* r);
+
+}  // namespace pt

@@ -1,0 +1,268 @@
+// lbvh.hip -- Morton-code LBVH build on gfx950 (replaces Acceleration("Trbvh"),
+// MinimalOptiX.cpp:378,494,534).  Steps and the shared per-element functions: pt_lbvh.h.
+// One thread per element in every kernel; the key sort and the index scan use rocPRIM.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "lbvh.h"
+#include "pt_lbvh.h"
+
+namespace pt {
+
+namespace {
+
+constexpr int kBlock = 256;
+inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
+
+struct SceneBox { uint32_t cLo[3], cHi[3], sLo[3], sHi[3]; };   // ordered-uint encoded
+
+__global__ void k_init_box(SceneBox* b) {
+  if (threadIdx.x < 3) {
+    b->cLo[threadIdx.x] = float_to_ordered(1e37f); b->cHi[threadIdx.x] = float_to_ordered(-1e37f);
+    b->sLo[threadIdx.x] = float_to_ordered(1e37f); b->sHi[threadIdx.x] = float_to_ordered(-1e37f);
+  }
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fminf_(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf_(v, __shfl_xor(v, o));
+  return v;
+}
+
+// 1. per-triangle bounds (meshBBox) + scene boxes
+__global__ void k_bounds(int n, const float* __restrict__ facePos, float* __restrict__ lo, float* __restrict__ hi, SceneBox* box) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  v3 l = mk3(1e37f, 1e37f, 1e37f), h = mk3(-1e37f, -1e37f, -1e37f), c = l, cM = h;
+  if (f < n) {
+    const float* p = facePos + 9 * (size_t)f;
+    tri_bounds(mk3(p[0], p[1], p[2]), mk3(p[3], p[4], p[5]), mk3(p[6], p[7], p[8]), l, h);
+    lo[3 * f] = l.x; lo[3 * f + 1] = l.y; lo[3 * f + 2] = l.z;
+    hi[3 * f] = h.x; hi[3 * f + 1] = h.y; hi[3 * f + 2] = h.z;
+    c = (l + h) * 0.5f; cM = c;
+  }
+  const float v[12] = { wave_min(c.x), wave_min(c.y), wave_min(c.z), wave_max(cM.x), wave_max(cM.y), wave_max(cM.z),
+                        wave_min(l.x), wave_min(l.y), wave_min(l.z), wave_max(h.x), wave_max(h.y), wave_max(h.z) };
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 3; k++) {
+      atomicMin(&box->cLo[k], float_to_ordered(v[k]));     atomicMax(&box->cHi[k], float_to_ordered(v[3 + k]));
+      atomicMin(&box->sLo[k], float_to_ordered(v[6 + k])); atomicMax(&box->sHi[k], float_to_ordered(v[9 + k]));
+    }
+  }
+}
+
+// 2. Morton keys
+__global__ void k_morton(int n, const float* __restrict__ lo, const float* __restrict__ hi, const SceneBox* box, uint64_t* __restrict__ keys) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const v3 clo = mk3(ordered_to_float(box->cLo[0]), ordered_to_float(box->cLo[1]), ordered_to_float(box->cLo[2]));
+  const v3 chi = mk3(ordered_to_float(box->cHi[0]), ordered_to_float(box->cHi[1]), ordered_to_float(box->cHi[2]));
+  const v3 invExt = mk3(inv_extent(clo.x, chi.x), inv_extent(clo.y, chi.y), inv_extent(clo.z, chi.z));
+  const v3 c = (mk3(lo[3 * f], lo[3 * f + 1], lo[3 * f + 2]) + mk3(hi[3 * f], hi[3 * f + 1], hi[3 * f + 2])) * 0.5f;
+  keys[f] = ((uint64_t)morton30(c, clo, invExt) << 32) | (uint32_t)f;
+}
+
+// 3. records + padded leaf boxes in sorted order
+__global__ void k_leaves(int n, const uint64_t* __restrict__ keys, const float* __restrict__ facePos,
+                         const float* __restrict__ faceNrm, const int* __restrict__ faceHasNrm, const int* __restrict__ faceMat,
+                         const float* __restrict__ lo, const float* __restrict__ hi, const SceneBox* box,
+                         Tri48* __restrict__ tris, TriShade* __restrict__ shade, float* __restrict__ leafLo, float* __restrict__ leafHi) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int f = (int)(keys[k] & 0xffffffffu);
+  const float* p = facePos + 9 * (size_t)f;
+  const v3 p0 = mk3(p[0], p[1], p[2]), p1 = mk3(p[3], p[4], p[5]), p2 = mk3(p[6], p[7], p[8]);
+  Tri48 t;
+  t.p0 = p0; t.e0 = p1 - p0; t.e1 = p0 - p2; t.mat = faceMat[f]; t.prim = f; t.pad = 0;
+  tris[k] = t;
+  TriShade sh;
+  sh.n0 = mk3(0, 0, 0); sh.n1 = sh.n0; sh.n2 = sh.n0; sh.hasNormals = 0; sh.pad1 = 0; sh.pad2 = 0;
+  if (faceNrm != nullptr && faceHasNrm != nullptr && faceHasNrm[f]) {
+    const float* q = faceNrm + 9 * (size_t)f;
+    sh.n0 = mk3(q[0], q[1], q[2]); sh.n1 = mk3(q[3], q[4], q[5]); sh.n2 = mk3(q[6], q[7], q[8]); sh.hasNormals = 1;
+  }
+  shade[k] = sh;
+  const float ex = ordered_to_float(box->sHi[0]) - ordered_to_float(box->sLo[0]);
+  const float ey = ordered_to_float(box->sHi[1]) - ordered_to_float(box->sLo[1]);
+  const float ez = ordered_to_float(box->sHi[2]) - ordered_to_float(box->sLo[2]);
+  const float padAbs = 1e-5f * fmaxf_(fmaxf_(ex, ey), ez) + 1e-30f;
+  for (int a = 0; a < 3; a++) { leafLo[3 * k + a] = pad_lo(lo[3 * f + a], padAbs); leafHi[3 * k + a] = pad_hi(hi[3 * f + a], padAbs); }
+}
+
+// 4. Karras radix tree
+__global__ void k_karras(int n, const uint64_t* __restrict__ keys, int* __restrict__ left, int* __restrict__ right,
+                         int* __restrict__ first, int* __restrict__ last, int* __restrict__ parentI, int* __restrict__ parentL) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const KarrasNode kn = karras_node(keys, n, i);
+  left[i] = kn.left; right[i] = kn.right; first[i] = kn.first; last[i] = kn.last;
+  if (kn.left < 0) parentL[~kn.left] = i; else parentI[kn.left] = i;
+  if (kn.right < 0) parentL[~kn.right] = i; else parentI[kn.right] = i;
+  if (i == 0) parentI[0] = -1;
+}
+
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 5. bottom-up fit: the second thread to arrive at a node unions the children and goes on.
+// Boxes of other workgroups are read/written with agent-scope accesses (they bypass the
+// non-coherent per-CU L1) and ordered by the fences around the arrival counter.
+__global__ void k_fit(int n, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ parentI,
+                      const int* __restrict__ parentL, const float* leafLo, const float* leafHi,
+                      float* ilo, float* ihi, unsigned int* arrivals) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int node = parentL[k];
+  while (node >= 0) {
+    __threadfence();
+    const unsigned int prev = atomicAdd(&arrivals[node], 1u);
+    if (prev == 0) return;                      // first arrival: the sibling subtree is not ready yet
+    __threadfence();
+    const int l = left[node], r = right[node];
+    float b[12];
+    for (int a = 0; a < 3; a++) {
+      const float ll = l < 0 ? ld_agent(&leafLo[3 * (~l) + a]) : ld_agent(&ilo[3 * l + a]);
+      const float rl = r < 0 ? ld_agent(&leafLo[3 * (~r) + a]) : ld_agent(&ilo[3 * r + a]);
+      const float lh = l < 0 ? ld_agent(&leafHi[3 * (~l) + a]) : ld_agent(&ihi[3 * l + a]);
+      const float rh = r < 0 ? ld_agent(&leafHi[3 * (~r) + a]) : ld_agent(&ihi[3 * r + a]);
+      b[a] = fminf_(ll, rl); b[3 + a] = fmaxf_(lh, rh);
+    }
+    for (int a = 0; a < 3; a++) { st_agent(&ilo[3 * node + a], b[a]); st_agent(&ihi[3 * node + a], b[3 + a]); }
+    node = parentI[node];
+  }
+}
+
+// 6a. which Karras nodes survive the collapse
+__global__ void k_kept(int ni, const int* __restrict__ first, const int* __restrict__ last, int leafSize, int* __restrict__ kept) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ni) kept[i] = (last[i] - first[i] + 1 > leafSize) ? 1 : 0;
+}
+
+// 6b. emit the compacted 64-byte nodes
+__global__ void k_emit(int ni, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ first,
+                       const int* __restrict__ last, const int* __restrict__ kept, const int* __restrict__ newIndex, int leafSize,
+                       const float* __restrict__ leafLo, const float* __restrict__ leafHi, const float* __restrict__ ilo,
+                       const float* __restrict__ ihi, Node64* __restrict__ nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ni || !kept[i]) return;
+  const int l = left[i], r = right[i];
+  const float* l0 = l < 0 ? leafLo + 3 * (~l) : ilo + 3 * l;
+  const float* h0 = l < 0 ? leafHi + 3 * (~l) : ihi + 3 * l;
+  const float* l1 = r < 0 ? leafLo + 3 * (~r) : ilo + 3 * r;
+  const float* h1 = r < 0 ? leafHi + 3 * (~r) : ihi + 3 * r;
+  Node64 nd;
+  nd.a.x = l0[0]; nd.a.y = l0[1]; nd.a.z = l0[2]; nd.a.w = h0[0];
+  nd.b.x = h0[1]; nd.b.y = h0[2]; nd.b.z = l1[0]; nd.b.w = l1[1];
+  nd.c.x = l1[2]; nd.c.y = h1[0]; nd.c.z = h1[1]; nd.c.w = h1[2];
+  nd.c0 = collapsed_ref(l, first, last, newIndex, leafSize);
+  nd.c1 = collapsed_ref(r, first, last, newIndex, leafSize);
+  nd.pad0 = 0; nd.pad1 = 0;
+  nodes[newIndex[i]] = nd;
+}
+
+// 7. depth of the emitted tree = longest chain of kept ancestors
+__global__ void k_depth(int ni, const int* __restrict__ kept, const int* __restrict__ parentI, int* depthOut) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int d = 0;
+  if (i < ni && kept[i]) { int p = i; while (p >= 0) { d++; p = parentI[p]; } }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) d = max(d, __shfl_xor(d, o));
+  if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(depthOut, d);
+}
+
+template <class T> hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, sizeof(T) * (n ? n : 1)); }
+
+}  // namespace
+
+void lbvh_free(LbvhResult* r) {
+  if (!r) return;
+  if (r->nodes) (void)hipFree(r->nodes);
+  if (r->tris) (void)hipFree(r->tris);
+  if (r->shade) (void)hipFree(r->shade);
+  *r = LbvhResult();
+}
+
+#define LB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
+
+hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dFaceNrm, const int* dFaceHasNrm,
+                      const int* dFaceMat, int n, int leafSize, LbvhResult* out) {
+  hipError_t err = hipSuccess;
+  *out = LbvhResult();
+  out->nTris = n; out->leafSize = leafSize;
+  if (n <= 0) return hipSuccess;
+  if (leafSize < 1) leafSize = 1;
+  if (leafSize > kMaxLeaf) leafSize = kMaxLeaf;
+  out->leafSize = leafSize;
+  const int ni = n - 1;
+
+  float *lo = nullptr, *hi = nullptr, *leafLo = nullptr, *leafHi = nullptr, *ilo = nullptr, *ihi = nullptr;
+  uint64_t *keys = nullptr, *keysSorted = nullptr;
+  int *left = nullptr, *right = nullptr, *first = nullptr, *last = nullptr, *parentI = nullptr, *parentL = nullptr, *kept = nullptr, *newIndex = nullptr;
+  unsigned int* arrivals = nullptr; SceneBox* box = nullptr; int* dDepth = nullptr; void* tmp = nullptr;
+  size_t tmpSort = 0, tmpScan = 0, tmpBytes = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int hostCount[2] = { 0, 0 };
+
+  LB_CHECK(hipEventCreate(&e0)); LB_CHECK(hipEventCreate(&e1));
+  LB_CHECK(dmalloc(&lo, 3 * (size_t)n)); LB_CHECK(dmalloc(&hi, 3 * (size_t)n));
+  LB_CHECK(dmalloc(&leafLo, 3 * (size_t)n)); LB_CHECK(dmalloc(&leafHi, 3 * (size_t)n));
+  LB_CHECK(dmalloc(&ilo, 3 * (size_t)ni)); LB_CHECK(dmalloc(&ihi, 3 * (size_t)ni));
+  LB_CHECK(dmalloc(&keys, (size_t)n)); LB_CHECK(dmalloc(&keysSorted, (size_t)n));
+  LB_CHECK(dmalloc(&left, (size_t)ni)); LB_CHECK(dmalloc(&right, (size_t)ni)); LB_CHECK(dmalloc(&first, (size_t)ni)); LB_CHECK(dmalloc(&last, (size_t)ni));
+  LB_CHECK(dmalloc(&parentI, (size_t)ni)); LB_CHECK(dmalloc(&parentL, (size_t)n)); LB_CHECK(dmalloc(&kept, (size_t)ni + 1)); LB_CHECK(dmalloc(&newIndex, (size_t)ni + 1));
+  LB_CHECK(dmalloc(&arrivals, (size_t)ni)); LB_CHECK(dmalloc(&box, 1)); LB_CHECK(dmalloc(&dDepth, 1));
+  LB_CHECK(dmalloc(&out->tris, (size_t)n)); LB_CHECK(dmalloc(&out->shade, (size_t)n));
+  LB_CHECK(rocprim::radix_sort_keys(nullptr, tmpSort, keys, keysSorted, (size_t)n, 0, 64, stream));
+  if (ni > 0) LB_CHECK(rocprim::exclusive_scan(nullptr, tmpScan, kept, newIndex, 0, (size_t)ni, rocprim::plus<int>(), stream));
+  tmpBytes = tmpSort > tmpScan ? tmpSort : tmpScan;
+  LB_CHECK(hipMalloc(&tmp, tmpBytes ? tmpBytes : 16));
+
+  LB_CHECK(hipEventRecord(e0, stream));
+  k_init_box<<<1, 64, 0, stream>>>(box);
+  k_bounds<<<grid_for(n), kBlock, 0, stream>>>(n, dFacePos, lo, hi, box);
+  k_morton<<<grid_for(n), kBlock, 0, stream>>>(n, lo, hi, box, keys);
+  LB_CHECK(rocprim::radix_sort_keys(tmp, tmpSort, keys, keysSorted, (size_t)n, 0, 64, stream));
+  k_leaves<<<grid_for(n), kBlock, 0, stream>>>(n, keysSorted, dFacePos, dFaceNrm, dFaceHasNrm, dFaceMat, lo, hi, box,
+                                               out->tris, out->shade, leafLo, leafHi);
+  if (n <= leafSize) {
+    out->rootRef = make_leaf_ref(0, n); out->nNodes = 0; out->depth = 0;
+    LB_CHECK(dmalloc(&out->nodes, 1));
+  } else {
+    LB_CHECK(hipMemsetAsync(arrivals, 0, sizeof(unsigned int) * (size_t)ni, stream));
+    LB_CHECK(hipMemsetAsync(dDepth, 0, sizeof(int), stream));
+    k_karras<<<grid_for(ni), kBlock, 0, stream>>>(n, keysSorted, left, right, first, last, parentI, parentL);
+    k_fit<<<grid_for(n), kBlock, 0, stream>>>(n, left, right, parentI, parentL, leafLo, leafHi, ilo, ihi, arrivals);
+    k_kept<<<grid_for(ni), kBlock, 0, stream>>>(ni, first, last, leafSize, kept);
+    LB_CHECK(rocprim::exclusive_scan(tmp, tmpScan, kept, newIndex, 0, (size_t)ni, rocprim::plus<int>(), stream));
+    LB_CHECK(hipMemcpyAsync(&hostCount[0], newIndex + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+    LB_CHECK(hipMemcpyAsync(&hostCount[1], kept + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+    LB_CHECK(hipStreamSynchronize(stream));
+    out->nNodes = hostCount[0] + hostCount[1];
+    LB_CHECK(dmalloc(&out->nodes, (size_t)out->nNodes));
+    k_emit<<<grid_for(ni), kBlock, 0, stream>>>(ni, left, right, first, last, kept, newIndex, leafSize, leafLo, leafHi, ilo, ihi, out->nodes);
+    k_depth<<<grid_for(ni), kBlock, 0, stream>>>(ni, kept, parentI, dDepth);
+    LB_CHECK(hipMemcpyAsync(&out->depth, dDepth, sizeof(int), hipMemcpyDeviceToHost, stream));
+    out->rootRef = 0;
+  }
+  LB_CHECK(hipEventRecord(e1, stream));
+  LB_CHECK(hipStreamSynchronize(stream));
+  LB_CHECK(hipGetLastError());
+  (void)hipEventElapsedTime(&out->buildMs, e0, e1);
+
+done:
+  for (void* p : { (void*)lo, (void*)hi, (void*)leafLo, (void*)leafHi, (void*)ilo, (void*)ihi, (void*)keys, (void*)keysSorted,
+                   (void*)left, (void*)right, (void*)first, (void*)last, (void*)parentI, (void*)parentL, (void*)kept, (void*)newIndex,
+                   (void*)arrivals, (void*)box, (void*)dDepth, tmp })
+    if (p) (void)hipFree(p);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (err != hipSuccess) lbvh_free(out);
+  return err;
+}
+
+}  // namespace pt

@@ -1,0 +1,519 @@
+// moptix_api.hip -- implementation of the C ABI of include/moptix.h on HIP (gfx950).
+// Host-side staging of the scene, upload, LBVH build, launches, read-back, measurement.
+// There is no CPU path: every entry point that computes needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/moptix.h"
+#include "lbvh.h"
+#include "megakernel.h"
+#include "pt_upload.h"
+
+using namespace pt;
+
+namespace {
+
+std::string g_lastError;   // errors without a context (create)
+
+template <class T> struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  hipError_t ensure(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t e = hipMalloc((void**)&p, sizeof(T) * (count ? count : 1));
+    if (e == hipSuccess) n = count ? count : 1;
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& v, hipStream_t s) {
+    hipError_t e = ensure(v.size());
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpyAsync(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, s);
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct moptix_context_t {
+  int device = 0;
+  int numCUs = 256;
+  hipStream_t stream = nullptr; bool ownStream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+
+  moptix_params params{}; bool haveParams = false;
+
+  // host staging (copied from the caller, as OptiX copies on setUserData / map+memcpy)
+  std::vector<DevMaterial> mats;
+  std::vector<DevSphere> spheres; std::vector<int> sphereMat;
+  std::vector<DevQuad> quads;
+  std::vector<DevLight> lights;
+  std::vector<float> facePos, faceNrm; std::vector<int> faceHasNrm, faceMat;
+  bool sceneDirty = true, accelBuilt = false;
+
+  // device
+  DevBuf<DevMaterial> dMats; DevBuf<DevSphere> dSpheres; DevBuf<int> dSphereMat; DevBuf<DevQuad> dQuads; DevBuf<DevLight> dLights;
+  DevBuf<float> dFacePos, dFaceNrm; DevBuf<int> dFaceHasNrm, dFaceMat;
+  LbvhResult bvh;
+  DevBuf<float> dAccum; float* accumBound = nullptr; size_t accumPixels = 0;
+  DevBuf<int> dSeeds; DevBuf<int> dWork; DevBuf<unsigned long long> dCounters; DevBuf<int> dOverflow; DevBuf<uint8_t> dRgb8;
+
+  int rank = 0, nRanks = 1;
+  int optExitThreshold = 40, optLeafSize = 4, optBlocksPerCU = 4, optVariant = 0;
+
+  double kernelMs = 0.0; uint64_t nLaunches = 0;
+  bool asyncPending = false;
+};
+
+namespace {
+
+int fail(moptix_context c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_lastError = msg;
+  return code;
+}
+int hipFail(moptix_context c, hipError_t e, const char* what) {
+  return fail(c, MOPTIX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(c, x, what) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hipFail((c), e_, (what)); } while (0)
+
+float* accum_ptr(moptix_context c) { return c->accumBound ? c->accumBound : c->dAccum.p; }
+
+int ensure_accum(moptix_context c) {
+  const size_t px = (size_t)c->params.width * c->params.height;
+  if (c->accumBound) { c->accumPixels = px; return MOPTIX_OK; }
+  if (c->dAccum.p && c->accumPixels == px) return MOPTIX_OK;
+  // createBuffer(RT_BUFFER_INPUT_OUTPUT, FLOAT3, W, H) zeroed by the host (MinimalOptiX.cpp:144-147)
+  HIPCHK(c, c->dAccum.ensure(3 * px), "alloc accuBuffer");
+  HIPCHK(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(float) * 3 * px, c->stream), "clear accuBuffer");
+  c->accumPixels = px;
+  return MOPTIX_OK;
+}
+
+void fill_view(moptix_context c, SceneView& v) {
+  memset(&v, 0, sizeof(v));
+  const moptix_params& p = c->params;
+  v.width = (int)p.width; v.height = (int)p.height;
+  v.maxDepth = (int)p.rayMaxDepth; v.minIntensity = p.rayMinIntensity; v.epsT = p.rayEpsilonT;
+  v.bg = to_v3(p.bgColor); v.cam = make_cam(p.cam);
+  v.nSpheres = (int)c->spheres.size(); v.spheres = c->dSpheres.p; v.sphereMat = c->dSphereMat.p;
+  v.nQuads = (int)c->quads.size(); v.quads = c->dQuads.p;
+  v.nLights = (int)c->lights.size(); v.lights = c->dLights.p;
+  v.nMaterials = (int)c->mats.size(); v.mats = c->dMats.p;
+  v.anyDisneyAnalytic = 0;
+  for (size_t i = 0; i < c->spheres.size(); i++) if (c->mats[c->sphereMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
+  for (size_t i = 0; i < c->quads.size(); i++) if (c->mats[c->quads[i].mat].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
+  v.nTris = c->bvh.nTris; v.rootRef = c->bvh.nTris > 0 ? c->bvh.rootRef : kEmptyRef;
+  v.nodes = c->bvh.nodes; v.tris = c->bvh.tris; v.triShade = c->bvh.shade;
+}
+
+int check_ready(moptix_context c) {
+  if (!c) return fail(nullptr, MOPTIX_ERR_INVALID, "null context");
+  if (!c->haveParams) return fail(c, MOPTIX_ERR_STATE, "moptix_set_params has not been called");
+  if (!c->accelBuilt) return fail(c, MOPTIX_ERR_STATE, "moptix_build_accel has not been called since the scene changed");
+  return MOPTIX_OK;
+}
+
+int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool counted, bool blocking, moptix_stats* stats) {
+  int rc = check_ready(c);
+  if (rc != MOPTIX_OK) return rc;
+  if (nSeeds < 0 || (nSeeds > 0 && !seeds)) return fail(c, MOPTIX_ERR_INVALID, "bad seeds");
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  if ((rc = ensure_accum(c)) != MOPTIX_OK) return rc;
+  if (nSeeds == 0) return MOPTIX_OK;
+
+  std::vector<int> hs(seeds, seeds + nSeeds);
+  HIPCHK(c, c->dSeeds.upload(hs, c->stream), "upload seeds");
+  HIPCHK(c, c->dWork.ensure(1), "alloc work counter");
+  HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, sizeof(int), c->stream), "zero work counter");
+
+  LaunchArgs a;
+  memset(&a, 0, sizeof(a));
+  fill_view(c, a.scene);
+  a.seeds = c->dSeeds.p; a.nSeeds = nSeeds; a.accum = accum_ptr(c); a.workCounter = c->dWork.p;
+  const int tilesX = ((int)c->params.width + 7) / 8, tilesY = ((int)c->params.height + 7) / 8;
+  const long long nTiles = (long long)tilesX * tilesY;
+  const long long localTiles = (nTiles - c->rank + c->nRanks - 1) / c->nRanks;
+  if (localTiles * 64 > 0x7fffffffLL) return fail(c, MOPTIX_ERR_LIMIT, "frame too large for 32-bit work counter");
+  a.nWork = (int)(localTiles * 64); a.tilesX = tilesX; a.rank = c->rank; a.nRanks = c->nRanks;
+  a.exitThreshold = c->optExitThreshold;
+  const int nBlocks = c->numCUs * c->optBlocksPerCU;
+  a.stackOverflow = nullptr;
+  if (c->bvh.depth > megakernel_lds_stack_entries()) {
+    const size_t need = (size_t)(c->bvh.depth - megakernel_lds_stack_entries() + 1) * nBlocks * 256;
+    HIPCHK(c, c->dOverflow.ensure(need), "alloc stack overflow area");
+    a.stackOverflow = c->dOverflow.p;
+  }
+  if (counted) {
+    HIPCHK(c, c->dCounters.ensure(16), "alloc counters");
+    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * 16, c->stream), "zero counters");
+    a.counters = c->dCounters.p;
+  }
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
+  HIPCHK(c, launch_megakernel(c->stream, a, nBlocks, counted), "launch megakernel");
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream), "event");
+  c->asyncPending = true;
+  if (!blocking) return MOPTIX_OK;
+  rc = moptix_sync(c);
+  if (rc != MOPTIX_OK) return rc;
+  if (counted && stats) {
+    unsigned long long h[16];
+    HIPCHK(c, hipMemcpy(h, c->dCounters.p, sizeof(h), hipMemcpyDeviceToHost), "read counters");
+    stats->samples = h[0]; stats->primaryRays = h[1]; stats->bounceRays = h[2]; stats->shadowRays = h[3];
+    stats->nodeFetches = h[4]; stats->triTests = h[5]; stats->closestHits = h[6]; stats->lightLoads = h[7];
+    stats->analyticTests = h[8]; stats->traversalSteps = h[9]; stats->activeLaneSteps = h[10];
+  }
+  return MOPTIX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* moptix_version(void) { return "minimaloptix_amd 0.1 (gfx950)"; }
+
+const char* moptix_last_error(moptix_context ctx) { return ctx ? ctx->err.c_str() : g_lastError.c_str(); }
+
+int moptix_create(moptix_context* out, int device) {
+  if (!out) return fail(nullptr, MOPTIX_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, MOPTIX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(nullptr, MOPTIX_ERR_INVALID, "device index out of range");
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return hipFail(nullptr, e, "hipSetDevice");
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return hipFail(nullptr, e, "hipGetDeviceProperties");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, MOPTIX_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  moptix_context c = new moptix_context_t();
+  c->device = device; c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipFail(nullptr, e, "hipStreamCreate"); }
+  c->ownStream = true;
+  if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) { delete c; return hipFail(nullptr, e, "hipEventCreate"); }
+  *out = c;
+  return MOPTIX_OK;
+}
+
+int moptix_destroy(moptix_context c) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->dMats.release(); c->dSpheres.release(); c->dSphereMat.release(); c->dQuads.release(); c->dLights.release();
+  c->dFacePos.release(); c->dFaceNrm.release(); c->dFaceHasNrm.release(); c->dFaceMat.release();
+  lbvh_free(&c->bvh);
+  c->dAccum.release(); c->dSeeds.release(); c->dWork.release(); c->dCounters.release(); c->dOverflow.release(); c->dRgb8.release();
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return MOPTIX_OK;
+}
+
+int moptix_set_stream(moptix_context c, void* hipStream) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  (void)hipStreamSynchronize(c->stream);
+  if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+  if (hipStream) { c->stream = (hipStream_t)hipStream; c->ownStream = false; }
+  else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate"); c->ownStream = true; }
+  return MOPTIX_OK;
+}
+
+int moptix_set_params(moptix_context c, const moptix_params* p) {
+  if (!c || !p) return fail(c, MOPTIX_ERR_INVALID, "null argument");
+  if (p->width == 0 || p->height == 0) return fail(c, MOPTIX_ERR_INVALID, "zero-sized launch");
+  const bool resized = !c->haveParams || p->width != c->params.width || p->height != c->params.height;
+  c->params = *p; c->haveParams = true;
+  if (resized && !c->accumBound) { c->accumPixels = 0; }
+  return MOPTIX_OK;
+}
+
+int moptix_clear_scene(moptix_context c) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  c->mats.clear(); c->spheres.clear(); c->sphereMat.clear(); c->quads.clear(); c->lights.clear();
+  c->facePos.clear(); c->faceNrm.clear(); c->faceHasNrm.clear(); c->faceMat.clear();
+  c->sceneDirty = true; c->accelBuilt = false;
+  return MOPTIX_OK;
+}
+
+int moptix_add_material(moptix_context c, const moptix_material* m, int32_t* outMatId) {
+  if (!c || !m) return fail(c, MOPTIX_ERR_INVALID, "null argument");
+  if (m->kind < MOPTIX_MAT_LAMBERTIAN || m->kind > MOPTIX_MAT_LIGHT) return fail(c, MOPTIX_ERR_INVALID, "unknown material kind");
+  c->mats.push_back(make_dev_material(*m));
+  if (outMatId) *outMatId = (int32_t)c->mats.size() - 1;
+  c->sceneDirty = true; c->accelBuilt = false;
+  return MOPTIX_OK;
+}
+
+static int check_mat(moptix_context c, int32_t id) {
+  if (id < 0 || id >= (int32_t)c->mats.size()) return fail(c, MOPTIX_ERR_INVALID, "material id out of range");
+  return MOPTIX_OK;
+}
+
+int moptix_add_spheres(moptix_context c, const moptix_sphere_params* s, const int32_t* matIds, int32_t n) {
+  if (!c || n < 0 || (n > 0 && (!s || !matIds))) return fail(c, MOPTIX_ERR_INVALID, "bad argument");
+  for (int32_t i = 0; i < n; i++) {
+    if (check_mat(c, matIds[i]) != MOPTIX_OK) return MOPTIX_ERR_INVALID;
+    c->spheres.push_back(make_dev_sphere(s[i])); c->sphereMat.push_back(matIds[i]);
+  }
+  c->sceneDirty = true; c->accelBuilt = false;
+  return MOPTIX_OK;
+}
+
+int moptix_add_quads(moptix_context c, const moptix_quad_params* q, const int32_t* matIds, int32_t n) {
+  if (!c || n < 0 || (n > 0 && (!q || !matIds))) return fail(c, MOPTIX_ERR_INVALID, "bad argument");
+  for (int32_t i = 0; i < n; i++) {
+    if (check_mat(c, matIds[i]) != MOPTIX_OK) return MOPTIX_ERR_INVALID;
+    c->quads.push_back(make_dev_quad(q[i], matIds[i]));
+  }
+  c->sceneDirty = true; c->accelBuilt = false;
+  return MOPTIX_OK;
+}
+
+int moptix_add_mesh(moptix_context c, const float* positions, int32_t nVerts, const float* normals, int32_t nNormals,
+                    const float* texcoords, int32_t nTexcoords, const int32_t* vIdx, const int32_t* nIdx, const int32_t* tIdx,
+                    int32_t nFaces, int32_t matId) {
+  (void)texcoords; (void)nTexcoords; (void)tIdx;   // texcoords feed only the texture path
+  if (!c || nFaces < 0 || nVerts < 0 || (nFaces > 0 && (!positions || !vIdx))) return fail(c, MOPTIX_ERR_INVALID, "bad argument");
+  if (check_mat(c, matId) != MOPTIX_OK) return MOPTIX_ERR_INVALID;
+  for (int32_t f = 0; f < 3 * nFaces; f++)
+    if (vIdx[f] < 0 || vIdx[f] >= nVerts) return fail(c, MOPTIX_ERR_INVALID, "vertex index out of range");
+  const bool meshHasNormals = normals && nNormals > 0 && nIdx;      // normalBuffer.size() != 0, Geometry.cu:136
+  for (int32_t f = 0; f < nFaces; f++) {
+    bool hasN = meshHasNormals;
+    for (int k = 0; k < 3; k++) {
+      const float* p = positions + 3 * (size_t)vIdx[3 * f + k];
+      c->facePos.push_back(p[0]); c->facePos.push_back(p[1]); c->facePos.push_back(p[2]);
+      if (hasN && (nIdx[3 * f + k] < 0 || nIdx[3 * f + k] >= nNormals)) hasN = false;
+    }
+    for (int k = 0; k < 3; k++) {
+      if (hasN) { const float* q = normals + 3 * (size_t)nIdx[3 * f + k]; c->faceNrm.push_back(q[0]); c->faceNrm.push_back(q[1]); c->faceNrm.push_back(q[2]); }
+      else { c->faceNrm.push_back(0.f); c->faceNrm.push_back(0.f); c->faceNrm.push_back(0.f); }
+    }
+    c->faceHasNrm.push_back(hasN ? 1 : 0);
+    c->faceMat.push_back(matId);
+  }
+  c->sceneDirty = true; c->accelBuilt = false;
+  return MOPTIX_OK;
+}
+
+int moptix_set_lights(moptix_context c, const moptix_light_params* lights, int32_t n) {
+  if (!c || n < 0 || (n > 0 && !lights)) return fail(c, MOPTIX_ERR_INVALID, "bad argument");
+  c->lights.clear();
+  for (int32_t i = 0; i < n; i++) {
+    if (lights[i].shape != MOPTIX_LIGHT_SPHERE && lights[i].shape != MOPTIX_LIGHT_QUAD) return fail(c, MOPTIX_ERR_INVALID, "No shape for light.");
+    c->lights.push_back(make_dev_light(lights[i]));
+  }
+  c->sceneDirty = true; c->accelBuilt = false;
+  return MOPTIX_OK;
+}
+
+int moptix_update_spheres(moptix_context c, int32_t first, const moptix_sphere_params* s, int32_t n) {
+  if (!c || !s || first < 0 || n < 0 || (size_t)first + (size_t)n > c->spheres.size()) return fail(c, MOPTIX_ERR_INVALID, "bad sphere range");
+  for (int32_t i = 0; i < n; i++) c->spheres[first + i] = make_dev_sphere(s[i]);
+  if (c->accelBuilt && n > 0) {
+    HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+    HIPCHK(c, hipMemcpyAsync(c->dSpheres.p + first, c->spheres.data() + first, sizeof(DevSphere) * n, hipMemcpyHostToDevice, c->stream), "update spheres");
+    HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+  }
+  return MOPTIX_OK;
+}
+
+int moptix_build_accel(moptix_context c, const char* kind) {
+  if (!c || !kind) return fail(c, MOPTIX_ERR_INVALID, "null argument");
+  const bool trbvh = !strcmp(kind, "Trbvh") || !strcmp(kind, "Lbvh");
+  if (!trbvh && strcmp(kind, "NoAccel")) return fail(c, MOPTIX_ERR_INVALID, std::string("unknown acceleration: ") + kind);
+  const int nFaces = (int)c->faceMat.size();
+  if (!trbvh && nFaces > 0) return fail(c, MOPTIX_ERR_INVALID, "NoAccel with triangle meshes is not supported; use Trbvh");
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  HIPCHK(c, c->dMats.upload(c->mats, c->stream), "upload materials");
+  HIPCHK(c, c->dSpheres.upload(c->spheres, c->stream), "upload spheres");
+  HIPCHK(c, c->dSphereMat.upload(c->sphereMat, c->stream), "upload sphere materials");
+  HIPCHK(c, c->dQuads.upload(c->quads, c->stream), "upload quads");
+  HIPCHK(c, c->dLights.upload(c->lights, c->stream), "upload lights");
+  lbvh_free(&c->bvh);
+  if (nFaces > 0) {
+    HIPCHK(c, c->dFacePos.upload(c->facePos, c->stream), "upload face positions");
+    HIPCHK(c, c->dFaceNrm.upload(c->faceNrm, c->stream), "upload face normals");
+    HIPCHK(c, c->dFaceHasNrm.upload(c->faceHasNrm, c->stream), "upload face flags");
+    HIPCHK(c, c->dFaceMat.upload(c->faceMat, c->stream), "upload face materials");
+    HIPCHK(c, lbvh_build(c->stream, c->dFacePos.p, c->dFaceNrm.p, c->dFaceHasNrm.p, c->dFaceMat.p, nFaces, c->optLeafSize, &c->bvh), "LBVH build");
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream), "sync after upload");
+  c->sceneDirty = false; c->accelBuilt = true;
+  return MOPTIX_OK;
+}
+
+int moptix_get_accel_info(moptix_context c, moptix_accel_info* out) {
+  if (!c || !out) return MOPTIX_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  out->nTriangles = (uint32_t)c->bvh.nTris; out->nNodes = (uint32_t)c->bvh.nNodes; out->maxLeafSize = (uint32_t)c->bvh.leafSize;
+  out->treeDepth = (uint32_t)c->bvh.depth; out->buildMs = c->bvh.buildMs;
+  out->nodeBytes = (uint64_t)c->bvh.nNodes * sizeof(Node64); out->triBytes = (uint64_t)c->bvh.nTris * sizeof(Tri48);
+  return MOPTIX_OK;
+}
+
+int moptix_validate(moptix_context c) {
+  int rc = check_ready(c);
+  if (rc != MOPTIX_OK) return rc;
+  if (c->mats.empty()) return fail(c, MOPTIX_ERR_STATE, "scene has no materials");
+  if (c->spheres.empty() && c->quads.empty() && c->faceMat.empty()) return fail(c, MOPTIX_ERR_STATE, "scene has no geometry");
+  for (const DevMaterial& m : c->mats)
+    if (m.kind == MAT_DISNEY && m.brdfType != BRDF_NORMAL && m.brdfType != BRDF_GLASS) return fail(c, MOPTIX_ERR_INVALID, "bad brdfType");
+  return MOPTIX_OK;
+}
+
+int moptix_launch(moptix_context c, int32_t randSeed) { return do_render(c, &randSeed, 1, false, true, nullptr); }
+int moptix_render(moptix_context c, const int32_t* seeds, int32_t nSeeds) { return do_render(c, seeds, nSeeds, false, true, nullptr); }
+int moptix_render_async(moptix_context c, const int32_t* seeds, int32_t nSeeds) { return do_render(c, seeds, nSeeds, false, false, nullptr); }
+int moptix_render_counted(moptix_context c, const int32_t* seeds, int32_t nSeeds, moptix_stats* out) {
+  if (out) memset(out, 0, sizeof(*out));
+  return do_render(c, seeds, nSeeds, true, true, out);
+}
+
+int moptix_sync(moptix_context c) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream), "stream synchronize");
+  if (c->asyncPending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) { c->kernelMs += ms; c->nLaunches++; }
+    c->asyncPending = false;
+  }
+  return MOPTIX_OK;
+}
+
+int moptix_set_partition(moptix_context c, int32_t rank, int32_t nRanks) {
+  if (!c || nRanks < 1 || rank < 0 || rank >= nRanks) return fail(c, MOPTIX_ERR_INVALID, "bad partition");
+  c->rank = rank; c->nRanks = nRanks;
+  return MOPTIX_OK;
+}
+
+int moptix_set_option(moptix_context c, const char* name, int32_t value) {
+  if (!c || !name) return MOPTIX_ERR_INVALID;
+  if (!strcmp(name, "exit_threshold")) { if (value < 0 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "exit_threshold in [0,64]"); c->optExitThreshold = value; }
+  else if (!strcmp(name, "leaf_size")) { if (value < 1 || value > kMaxLeaf) return fail(c, MOPTIX_ERR_INVALID, "leaf_size in [1,8]"); if (value != c->optLeafSize) c->accelBuilt = false; c->optLeafSize = value; }
+  else if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) return fail(c, MOPTIX_ERR_INVALID, "blocks_per_cu in [1,8]"); c->optBlocksPerCU = value; }
+  else if (!strcmp(name, "kernel_variant")) { c->optVariant = value; }
+  else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
+  return MOPTIX_OK;
+}
+
+int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
+  if (!c || !name || !value) return MOPTIX_ERR_INVALID;
+  if (!strcmp(name, "exit_threshold")) *value = c->optExitThreshold;
+  else if (!strcmp(name, "leaf_size")) *value = c->optLeafSize;
+  else if (!strcmp(name, "blocks_per_cu")) *value = c->optBlocksPerCU;
+  else if (!strcmp(name, "kernel_variant")) *value = c->optVariant;
+  else if (!strcmp(name, "num_cus")) *value = c->numCUs;
+  else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
+  return MOPTIX_OK;
+}
+
+int moptix_accum_read(moptix_context c, float* dstHost) {
+  if (!c || !dstHost) return fail(c, MOPTIX_ERR_INVALID, "null argument");
+  if (!c->haveParams) return fail(c, MOPTIX_ERR_STATE, "no params");
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  int rc = ensure_accum(c);
+  if (rc != MOPTIX_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(dstHost, accum_ptr(c), sizeof(float) * 3 * c->accumPixels, hipMemcpyDeviceToHost, c->stream), "read accuBuffer");
+  HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+  return MOPTIX_OK;
+}
+
+int moptix_accum_clear(moptix_context c) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  if (!c->haveParams) return fail(c, MOPTIX_ERR_STATE, "no params");
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  int rc = ensure_accum(c);
+  if (rc != MOPTIX_OK) return rc;
+  HIPCHK(c, hipMemsetAsync(accum_ptr(c), 0, sizeof(float) * 3 * c->accumPixels, c->stream), "clear accuBuffer");
+  HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+  return MOPTIX_OK;
+}
+
+int moptix_accum_device_ptr(moptix_context c, void** devPtr) {
+  if (!c || !devPtr) return MOPTIX_ERR_INVALID;
+  if (!c->haveParams) return fail(c, MOPTIX_ERR_STATE, "no params");
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  int rc = ensure_accum(c);
+  if (rc != MOPTIX_OK) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+  *devPtr = accum_ptr(c);
+  return MOPTIX_OK;
+}
+
+int moptix_accum_bind(moptix_context c, void* devPtr) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  c->accumBound = (float*)devPtr;
+  c->accumPixels = 0;
+  return MOPTIX_OK;
+}
+
+int moptix_resolve_rgb8(moptix_context c, float nAccumulation, int clearBuffer, uint8_t* dstHost) {
+  if (!c || !dstHost) return fail(c, MOPTIX_ERR_INVALID, "null argument");
+  if (!c->haveParams) return fail(c, MOPTIX_ERR_STATE, "no params");
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  int rc = ensure_accum(c);
+  if (rc != MOPTIX_OK) return rc;
+  const size_t bytes = 3 * c->accumPixels;
+  HIPCHK(c, c->dRgb8.ensure(bytes), "alloc rgb8");
+  HIPCHK(c, launch_resolve_rgb8(c->stream, accum_ptr(c), (int)c->params.width, (int)c->params.height, nAccumulation, clearBuffer, c->dRgb8.p), "resolve kernel");
+  HIPCHK(c, hipMemcpyAsync(dstHost, c->dRgb8.p, bytes, hipMemcpyDeviceToHost, c->stream), "read rgb8");
+  HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+  return MOPTIX_OK;
+}
+
+int moptix_kernel_time(moptix_context c, double* totalMs, uint64_t* nLaunches, int reset) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  if (totalMs) *totalMs = c->kernelMs;
+  if (nLaunches) *nLaunches = c->nLaunches;
+  if (reset) { c->kernelMs = 0.0; c->nLaunches = 0; }
+  return MOPTIX_OK;
+}
+
+int moptix_debug_read_accel(moptix_context c, void* nodes, void* tris, int32_t* triPrimIds) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  if (!c->accelBuilt) return fail(c, MOPTIX_ERR_STATE, "no acceleration structure");
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  if (nodes && c->bvh.nNodes > 0) HIPCHK(c, hipMemcpy(nodes, c->bvh.nodes, sizeof(Node64) * c->bvh.nNodes, hipMemcpyDeviceToHost), "read nodes");
+  if ((tris || triPrimIds) && c->bvh.nTris > 0) {
+    std::vector<Tri48> h(c->bvh.nTris);
+    HIPCHK(c, hipMemcpy(h.data(), c->bvh.tris, sizeof(Tri48) * c->bvh.nTris, hipMemcpyDeviceToHost), "read tris");
+    if (tris) memcpy(tris, h.data(), sizeof(Tri48) * h.size());
+    if (triPrimIds) for (size_t i = 0; i < h.size(); i++) triPrimIds[i] = h[i].prim;
+  }
+  return MOPTIX_OK;
+}
+
+int moptix_debug_trace(moptix_context c, const float* rays, int32_t n, float* outT, int32_t* outPrim) {
+  int rc = check_ready(c);
+  if (rc != MOPTIX_OK) return rc;
+  if (n < 0 || (n > 0 && (!rays || !outT || !outPrim))) return fail(c, MOPTIX_ERR_INVALID, "bad argument");
+  if (n == 0) return MOPTIX_OK;
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  float *dR = nullptr, *dT = nullptr; int* dP = nullptr; int* dOvf = nullptr;
+  HIPCHK(c, hipMalloc((void**)&dR, sizeof(float) * 8 * (size_t)n), "alloc rays");
+  HIPCHK(c, hipMalloc((void**)&dT, sizeof(float) * (size_t)n), "alloc t");
+  HIPCHK(c, hipMalloc((void**)&dP, sizeof(int) * (size_t)n), "alloc prim");
+  if (c->bvh.depth > megakernel_lds_stack_entries()) {
+    const size_t threads = ((size_t)n + 255) / 256 * 256;
+    HIPCHK(c, hipMalloc((void**)&dOvf, sizeof(int) * threads * (size_t)(c->bvh.depth - megakernel_lds_stack_entries() + 1)), "alloc overflow");
+  }
+  SceneView v; fill_view(c, v);
+  hipError_t e = hipMemcpyAsync(dR, rays, sizeof(float) * 8 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = launch_debug_trace(c->stream, v, dR, n, dT, dP, dOvf);
+  if (e == hipSuccess) e = hipMemcpyAsync(outT, dT, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(outPrim, dP, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dR); (void)hipFree(dT); (void)hipFree(dP); if (dOvf) (void)hipFree(dOvf);
+  if (e != hipSuccess) return hipFail(c, e, "debug trace");
+  return MOPTIX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// pt_lbvh.h -- building blocks of the Morton-code LBVH that replaces
+// Acceleration("Trbvh") (MinimalOptiX.cpp:378,494,534; closed source in OptiX).
+//
+//   1. per-triangle bounds + centroid                      (meshBBox, Geometry.cu:162-175)
+//   2. 30-bit Morton code of the centroid in the scene box; key = code<<32 | face  (unique)
+//   3. radix sort of the keys
+//   4. Karras 2012 radix tree over the sorted keys (one thread per internal node)
+//   5. bottom-up box fit with one atomic arrival counter per node
+//   6. collapse: every subtree with <= leafSize triangles becomes one leaf
+//      (first,count) in sorted order; surviving nodes are compacted and emitted as
+//      64-byte two-child nodes
+//
+// All steps are pure functions of the key order (min/max unions are exact), so the tree is
+// bit-reproducible; tests/hostsim runs the same functions sequentially on the host and the
+// GPU tests compare the device tree with that mirror word for word.
+#pragma once
+#include "pt_types.h"
+
+namespace pt {
+
+PT_HD uint32_t expand_bits10(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+// p = centroid, lo/invExt = scene centroid box; 10 bits per axis, x most significant
+PT_HD uint32_t morton30(v3 p, v3 lo, v3 invExt) {
+  const v3 n = (p - lo) * invExt;
+  const float fx = fminf_(fmaxf_(n.x * 1024.0f, 0.0f), 1023.0f);
+  const float fy = fminf_(fmaxf_(n.y * 1024.0f, 0.0f), 1023.0f);
+  const float fz = fminf_(fmaxf_(n.z * 1024.0f, 0.0f), 1023.0f);
+  return (expand_bits10((uint32_t)fx) << 2) | (expand_bits10((uint32_t)fy) << 1) | expand_bits10((uint32_t)fz);
+}
+PT_HD float inv_extent(float lo, float hi) { const float e = hi - lo; return e > 0.0f ? 1.0f / e : 0.0f; }
+
+PT_HD void tri_bounds(v3 p0, v3 p1, v3 p2, v3& lo, v3& hi) {
+  lo = mk3(fminf_(fminf_(p0.x, p1.x), p2.x), fminf_(fminf_(p0.y, p1.y), p2.y), fminf_(fminf_(p0.z, p1.z), p2.z));
+  hi = mk3(fmaxf_(fmaxf_(p0.x, p1.x), p2.x), fmaxf_(fmaxf_(p0.y, p1.y), p2.y), fmaxf_(fmaxf_(p0.z, p1.z), p2.z));
+}
+// conservative padding of a leaf box (see pt_path.h slab())
+PT_HD float pad_lo(float v, float padAbs) { return v - (padAbs + 1e-6f * __builtin_fabsf(v)); }
+PT_HD float pad_hi(float v, float padAbs) { return v + (padAbs + 1e-6f * __builtin_fabsf(v)); }
+
+// order-preserving float <-> uint mapping for atomicMin/atomicMax on floats
+PT_HD uint32_t float_to_ordered(float f) { uint32_t u = (uint32_t)f2i(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+PT_HD float ordered_to_float(uint32_t u) { return i2f((int32_t)((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u)); }
+
+PT_HD int clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
+// common-prefix length of keys i and j (-1 outside the array); keys are unique
+PT_HD int lcp(const uint64_t* keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  return clz64(keys[i] ^ keys[j]);
+}
+
+// child reference inside the *uncollapsed* Karras tree: >=0 internal node, <0 -> ~sortedLeaf
+struct KarrasNode { int left, right, first, last; };
+
+// Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", 2012, Alg. 1
+PT_HD KarrasNode karras_node(const uint64_t* keys, int n, int i) {
+  const int d = (lcp(keys, n, i, i + 1) - lcp(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = lcp(keys, n, i, i - d);
+  int lmax = 2;
+  while (lcp(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (lcp(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = lcp(keys, n, i, j);
+  int s = 0;
+  int t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (lcp(keys, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + (d < 0 ? d : 0);
+  KarrasNode kn;
+  kn.first = i < j ? i : j;
+  kn.last = i < j ? j : i;
+  kn.left = (kn.first == gamma) ? ~gamma : gamma;
+  kn.right = (kn.last == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
+  return kn;
+}
+
+// reference of a Karras child in the collapsed tree
+//   leaf i                      -> leaf ref (i,1)
+//   internal c, count<=leafSize -> leaf ref (first,count)
+//   internal c otherwise        -> new (compacted) index
+PT_HD int collapsed_ref(int child, const int* first, const int* last, const int* newIndex, int leafSize) {
+  if (child < 0) return make_leaf_ref(~child, 1);
+  const int count = last[child] - first[child] + 1;
+  if (count <= leafSize) return make_leaf_ref(first[child], count);
+  return newIndex[child];
+}
+
+}  // namespace pt

@@ -1,0 +1,96 @@
+// pt_math.h -- float3 arithmetic for the path-tracing megakernel (gfx950).
+//
+// Implements the arithmetic contract of DESIGN.md (AC1..AC7) so that the HIP
+// kernels take exactly the same ray/hit/sampling decisions as the CPU oracle:
+//   AC1 dot  = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+//   AC2 cross= ( fma(a.y,b.z,-(a.z*b.y)), ... )
+//   AC3 length = sqrtf(dot), normalize = v*(1/sqrtf(dot)), v/s = v*(1/s)
+//   AC4 every other operator is a single IEEE binary32 op (build with -ffp-contract=off)
+//   AC5 sin/cos evaluated in binary64 and rounded once
+//   AC7 point on ray = fma(t, d, o)
+// These are the optixu_math_namespace.h semantics the reference's programs rely on
+// (SURVEY.md Appendix A1), with the fused forms nvcc's default -fmad=true produces.
+//
+// The header is plain C++ so that tests/hostsim can compile the per-lane code for the
+// host and compare it with the oracle without a GPU; the product only ever runs it on
+// the device.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define PT_HD __host__ __device__ __forceinline__
+#define PT_D __device__ __forceinline__
+#else
+#define PT_HD inline
+#define PT_D inline
+#endif
+
+namespace pt {
+
+struct v3 { float x, y, z; };
+struct alignas(16) v4 { float x, y, z, w; };
+
+PT_HD v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_HD v3 splat3(float s) { return mk3(s, s, s); }
+PT_HD v3 xyz(const v4& a) { return mk3(a.x, a.y, a.z); }
+PT_HD v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_HD v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_HD v3 operator*(v3 a, v3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_HD v3 operator*(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_HD v3 operator*(float s, v3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_HD v3 operator+(v3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
+PT_HD v3 operator-(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+PT_HD v3 operator/(v3 a, float s) { float inv = 1.0f / s; return a * inv; }   // AC3
+
+PT_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PT_HD float dot(v3 a, v3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }                 // AC1
+PT_HD v3 cross(v3 a, v3 b) {                                                                        // AC2
+  return mk3(fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x)));
+}
+PT_HD float length(v3 a) { return __builtin_sqrtf(dot(a, a)); }
+PT_HD v3 normalize(v3 a) { float inv = 1.0f / __builtin_sqrtf(dot(a, a)); return a * inv; }
+PT_HD v3 ray_at(v3 o, v3 d, float t) { return mk3(fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z)); }  // AC7
+PT_HD float lerp(float a, float b, float t) { return a + t * (b - a); }
+PT_HD v3 lerp(v3 a, v3 b, float t) { return a + (b - a) * t; }
+PT_HD float fminf_(float a, float b) { return __builtin_fminf(a, b); }
+PT_HD float fmaxf_(float a, float b) { return __builtin_fmaxf(a, b); }
+PT_HD float clampf(float x, float lo, float hi) { return fmaxf_(lo, fminf_(x, hi)); }
+PT_HD float sqr(float x) { return x * x; }
+PT_HD float sin_ac(float x) { return (float)sin((double)x); }     // AC5
+PT_HD float cos_ac(float x) { return (float)cos((double)x); }
+
+PT_HD int32_t f2i(float f) { return __builtin_bit_cast(int32_t, f); }
+PT_HD float i2f(int32_t i) { return __builtin_bit_cast(float, i); }
+
+constexpr float kPi = 3.14159265358979323846f;   // M_PIf
+constexpr float kRtDefaultMax = 1e27f;           // RT_DEFAULT_MAX
+
+// optixu reflect / faceforward / refract
+PT_HD v3 reflect(v3 i, v3 n) { return i - (n * 2.0f) * dot(n, i); }
+PT_HD v3 faceforward(v3 n, v3 i, v3 nref) { return n * __builtin_copysignf(1.0f, dot(i, nref)); }
+PT_HD bool refract(v3& r, v3 i, v3 n, float ior) {
+  v3 nn = n;
+  float negNdotV = dot(i, nn);
+  float eta;
+  if (negNdotV > 0.0f) { eta = ior; nn = -n; negNdotV = -negNdotV; }
+  else { eta = 1.0f / ior; }
+  const float k = 1.0f - eta * eta * (1.0f - negNdotV * negNdotV);
+  if (k < 0.0f) { r = mk3(0.f, 0.f, 0.f); return false; }
+  r = normalize(i * eta - nn * (eta * negNdotV + __builtin_sqrtf(k)));
+  return true;
+}
+
+// optix::Onb
+struct Onb { v3 tangent, binormal, normal; };
+PT_HD Onb make_onb(v3 n) {
+  Onb o; o.normal = n;
+  if (__builtin_fabsf(n.x) > __builtin_fabsf(n.z)) o.binormal = mk3(-n.y, n.x, 0.f);
+  else                                             o.binormal = mk3(0.f, -n.z, n.y);
+  o.binormal = normalize(o.binormal);
+  o.tangent = cross(o.binormal, o.normal);
+  return o;
+}
+PT_HD v3 onb_inverse(const Onb& o, v3 p) { return (o.tangent * p.x + o.binormal * p.y) + o.normal * p.z; }
+
+}  // namespace pt

@@ -1,0 +1,376 @@
+// pt_path.h -- the per-lane path state machine and the resumable BVH traversal that the
+// megakernel runs.  The reference's recursion
+//     camera -> rtTrace -> closest-hit -> rtTrace -> ...      
+// is flattened into   L = sum_k (prod_{j<k} w_j) * e_k   with the RNG draw order and the
+// seed forks of SURVEY A2 preserved, so a lane always owns exactly one ray in flight:
+//
+//   M_NEW_PIXEL -> M_NEW_SAMPLE -> [M_TRACE -> M_RESULT (-> M_LIGHTS -> M_TRACE ...)]* -> M_NEW_SAMPLE
+//
+// Traversal state (Trav) lives in registers + an LDS stack and is resumable at any step,
+// which is what lets the kernel leave the traversal loop when too few lanes of the wave
+// are still traversing (wave-level re-fill) and come back later.
+#pragma once
+#include "pt_types.h"
+#include "pt_rng.h"
+#include "pt_geom.h"
+#include "pt_disney.h"
+
+namespace pt {
+
+enum { M_NEW_PIXEL = 0, M_NEW_SAMPLE = 1, M_TRACE = 2, M_RESULT = 3, M_LIGHTS = 4, M_DONE = 5 };
+enum { RK_RADIANCE = 0, RK_SHADOW = 1 };   // MinimalOptiX.h:48 RayType
+
+struct Counters {
+  uint32_t samples, primaryRays, bounceRays, shadowRays;
+  uint32_t nodeFetches, triTests, closestHits, lightLoads, analyticTests;
+};
+template <bool CNT> PT_HD void cnt(uint32_t& c, uint32_t n = 1) { if (CNT) c += n; }
+
+struct Trav {
+  int node;        // current node/leaf reference; kTravDone when the ray is finished
+  int sp;          // stack entries in use
+  int started;     // analytic lists done, BVH walk in progress
+  float tbest;     // radiance: nearest accepted t so far; shadow: the ray's tmax
+  int bestPrim;    // primitive id of the nearest hit (spheres, quads, triangles) or -1
+  int bestTri;     // record index of the nearest triangle, or -1
+  float beta, gamma;
+  v3 att;          // shadow attenuation (disneyAnyHit)
+  v3 inv;          // 1/d
+};
+
+struct PathState {
+  int mode;
+  int pixel;           // y*W + x
+  int sample;          // index of the next launch seed
+  v3 accum;            // accuBuffer[pixel] carried in registers across the samples
+  v3 thr, rad;         // path throughput and accumulated radiance of the current sample
+  int depth; uint32_t seed;
+  v3 o, d; float tmin, tmax; int kind;    // the ray in flight
+  v3 N, V; int mat; int light;            // Disney hit context while its lights are looped
+  v3 pendW; float pendInv;                // weight of the shadow ray in flight
+};
+
+// ---------------------------------------------------------------------------------------
+// Traversal
+// ---------------------------------------------------------------------------------------
+
+// disneyAnyHit (Material.cu:225-232). Returns true when the ray is terminated.
+PT_HD bool shadow_any_hit(const SceneView& sc, int mat, v3& att) {
+  const DevMaterial& m = sc.mats[mat];
+  if (m.kind != MAT_DISNEY) return false;                 // no any-hit program: does not occlude
+  if (m.brdfType == BRDF_GLASS) { att = att * m.color; return false; }
+  att = mk3(0.f, 0.f, 0.f);
+  return true;                                            // rtTerminateRay
+}
+
+// Brute-force lists ("NoAccel" groups and the light geometry) + set-up of the BVH walk.
+template <bool CNT>
+PT_HD void trav_begin(const SceneView& sc, const PathState& ps, Trav& tv, Counters& ct) {
+  tv.tbest = ps.tmax; tv.bestPrim = -1; tv.bestTri = -1; tv.beta = 0.f; tv.gamma = 0.f;
+  tv.att = mk3(1.f, 1.f, 1.f);
+  tv.inv = mk3(1.0f / ps.d.x, 1.0f / ps.d.y, 1.0f / ps.d.z);
+  tv.sp = 0; tv.started = 1;
+  bool terminated = false;
+  if (ps.kind == RK_RADIANCE) {
+    for (int i = 0; i < sc.nSpheres; i++) {               // sphereIntersect, Geometry.cu:18-55
+      const DevSphere s = sc.spheres[i];
+      float t1, t2;
+      if (sphere_roots(s.center, s.radius, ps.o, ps.d, t1, t2)) {
+        if (potential(t1, i, ps.tmin, tv.tbest, tv.bestPrim)) { tv.tbest = t1; tv.bestPrim = i; }
+        else if (potential(t2, i, ps.tmin, tv.tbest, tv.bestPrim)) { tv.tbest = t2; tv.bestPrim = i; }
+      }
+    }
+    for (int i = 0; i < sc.nQuads; i++) {                 // quadIntersect, Geometry.cu:70-91
+      const DevQuad q = sc.quads[i];
+      float t; const int id = sc.nSpheres + i;
+      if (quad_test(q.plane, q.v1, q.v2, q.anchor, ps.o, ps.d, ps.tmin, ps.tmax, t) &&
+          potential(t, id, ps.tmin, tv.tbest, tv.bestPrim)) { tv.tbest = t; tv.bestPrim = id; }
+    }
+    cnt<CNT>(ct.analyticTests, (uint32_t)(sc.nSpheres + sc.nQuads));
+  } else if (sc.anyDisneyAnalytic) {
+    for (int i = 0; i < sc.nSpheres && !terminated; i++) {
+      const int mat = sc.sphereMat[i];
+      if (sc.mats[mat].kind != MAT_DISNEY) continue;
+      const DevSphere s = sc.spheres[i];
+      float t1, t2;
+      if (sphere_roots(s.center, s.radius, ps.o, ps.d, t1, t2) &&
+          ((t1 > ps.tmin && t1 < ps.tmax) || (t2 > ps.tmin && t2 < ps.tmax)))
+        terminated = shadow_any_hit(sc, mat, tv.att);
+    }
+    for (int i = 0; i < sc.nQuads && !terminated; i++) {
+      const DevQuad q = sc.quads[i];
+      if (sc.mats[q.mat].kind != MAT_DISNEY) continue;
+      float t;
+      if (quad_test(q.plane, q.v1, q.v2, q.anchor, ps.o, ps.d, ps.tmin, ps.tmax, t))
+        terminated = shadow_any_hit(sc, q.mat, tv.att);
+    }
+    cnt<CNT>(ct.analyticTests, (uint32_t)(sc.nSpheres + sc.nQuads));
+  }
+  tv.node = (terminated || sc.rootRef == kEmptyRef) ? kTravDone : sc.rootRef;
+}
+
+// Conservative slab test of one child box.  Never culls a box whose triangles the exact
+// test could accept: node boxes are padded at build time and the far bound gets one ulp of
+// slack; "<=" keeps boxes that start exactly at tbest (needed for the equal-t rule).
+PT_HD bool slab(v3 lo, v3 hi, v3 o, v3 inv, float tmin, float tmax, float& tn) {
+  float t0x = (lo.x - o.x) * inv.x, t1x = (hi.x - o.x) * inv.x;
+  float t0y = (lo.y - o.y) * inv.y, t1y = (hi.y - o.y) * inv.y;
+  float t0z = (lo.z - o.z) * inv.z, t1z = (hi.z - o.z) * inv.z;
+  tn = fmaxf_(fmaxf_(fminf_(t0x, t1x), fminf_(t0y, t1y)), fmaxf_(fminf_(t0z, t1z), tmin));
+  float tf = fminf_(fminf_(fmaxf_(t0x, t1x), fmaxf_(t0y, t1y)), fminf_(fmaxf_(t0z, t1z), tmax));
+  return tn <= tf * 1.0000005f;
+}
+
+template <class Stack>
+PT_HD void trav_pop(Trav& tv, Stack& st) {
+  if (tv.sp == 0) tv.node = kTravDone;
+  else { tv.sp--; tv.node = st.load(tv.sp); }
+}
+
+// One traversal step for a lane with tv.node != kTravDone: either one two-child node
+// (one 64-byte fetch) or one leaf (count x 48-byte triangle records).
+template <bool CNT, class Stack>
+PT_HD void trav_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
+  if (tv.node >= 0) {
+    const Node64* np = sc.nodes + tv.node;
+    const v4 a = np->a, b = np->b, c = np->c;
+    const int c0 = np->c0, c1 = np->c1;
+    cnt<CNT>(ct.nodeFetches);
+    float tn0, tn1;
+    const bool h0 = slab(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), ps.o, tv.inv, ps.tmin, tv.tbest, tn0);
+    const bool h1 = slab(mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), ps.o, tv.inv, ps.tmin, tv.tbest, tn1);
+    if (h0 & h1) {
+      const bool firstIs0 = tn0 <= tn1;
+      st.store(tv.sp, firstIs0 ? c1 : c0); tv.sp++;
+      tv.node = firstIs0 ? c0 : c1;
+    } else if (h0) tv.node = c0;
+    else if (h1) tv.node = c1;
+    else trav_pop(tv, st);
+  } else {
+    const int first = leaf_first(tv.node), count = leaf_count(tv.node);
+    const int triBase = sc.nSpheres + sc.nQuads;
+    bool terminated = false;
+    for (int k = 0; k < count; k++) {
+      const Tri48* tp = sc.tris + (first + k);
+      const v3 p0 = tp->p0, e0 = tp->e0, e1 = tp->e1;
+      const int mat = tp->mat, prim = tp->prim;
+      cnt<CNT>(ct.triTests);
+      v3 n; float t, be, ga;
+      if (tri_test(ps.o, ps.d, ps.tmin, ps.tmax, p0, e0, e1, n, t, be, ga)) {     // meshIntersect, Geometry.cu:121-160
+        if (ps.kind == RK_RADIANCE) {
+          if (potential(t, triBase + prim, ps.tmin, tv.tbest, tv.bestPrim)) {
+            tv.tbest = t; tv.bestPrim = triBase + prim; tv.bestTri = first + k; tv.beta = be; tv.gamma = ga;
+          }
+        } else if (shadow_any_hit(sc, mat, tv.att)) { terminated = true; break; }
+      }
+    }
+    if (terminated) tv.node = kTravDone;
+    else trav_pop(tv, st);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Path state machine
+// ---------------------------------------------------------------------------------------
+
+// Camera.cu:21-38: per-pixel seed, thin-lens offset, jittered pixel, primary ray
+template <bool CNT>
+PT_HD void begin_sample(const SceneView& sc, PathState& ps, int launchSeed, Counters& ct) {
+  const int x = ps.pixel % sc.width, y = ps.pixel / sc.width;
+  ps.depth = 1;
+  ps.seed = tea16((uint32_t)y * (uint32_t)sc.width + (uint32_t)x, (uint32_t)launchSeed);
+  ps.thr = mk3(1.f, 1.f, 1.f); ps.rad = mk3(0.f, 0.f, 0.f);
+  const v3 randInLens = rand_in_unit_disk(ps.seed) * sc.cam.lensRadius;
+  const v3 offs = sc.cam.u * randInLens.x + sc.cam.v * randInLens.y;
+  const float r1 = rnd(ps.seed); const float r2 = rnd(ps.seed);
+  const float xyx = ((float)x + r1 - 0.5f) / (float)sc.width;
+  const float xyy = ((float)y + r2 - 0.5f) / (float)sc.height;
+  ps.o = sc.cam.origin + offs;
+  ps.d = normalize((((sc.cam.scrLowerLeftCorner + sc.cam.horizontal * xyx) + sc.cam.vertical * xyy) - sc.cam.origin) - offs);
+  ps.tmin = sc.epsT; ps.tmax = kRtDefaultMax; ps.kind = RK_RADIANCE;
+  ps.mode = M_TRACE;
+  cnt<CNT>(ct.samples); cnt<CNT>(ct.primaryRays);
+}
+
+// Camera.cu:39-41: clamp the sample and add it to the accumulator
+PT_HD void end_sample(PathState& ps) {
+  ps.accum = ps.accum + mk3(clampf(ps.rad.x, 0.f, 1.f), clampf(ps.rad.y, 0.f, 1.f), clampf(ps.rad.z, 0.f, 1.f));
+  ps.sample++;
+  ps.mode = M_NEW_SAMPLE;
+}
+
+// continuation ray of a closest-hit program: child payload = folkPayload(parent)
+PT_HD void bounce(const SceneView& sc, PathState& ps, v3 o, v3 d, uint32_t childSeed) {
+  ps.o = o; ps.d = d; ps.tmin = sc.epsT; ps.tmax = kRtDefaultMax; ps.kind = RK_RADIANCE;
+  ps.depth++; ps.seed = childSeed;
+  ps.mode = M_TRACE;
+}
+
+// Material.cu:72-110 glass and :134-168 Disney GLASS branch (fork the seed, THEN draw)
+template <bool CNT>
+PT_HD void glass_body(const SceneView& sc, PathState& ps, float ior, v3 tint, const HitAttr& h, Counters& ct) {
+  v3 normal = h.shadingNormal;
+  float cosThetaI = -dot(ps.d, normal);
+  float refIdx;
+  if (cosThetaI > 0.f) { refIdx = ior; }
+  else { refIdx = 1.f / ior; cosThetaI = -cosThetaI; normal = -normal; }
+  v3 refracted;
+  const bool totalReflection = !refract(refracted, ps.d, normal, refIdx);
+  const float cosThetaT = -dot(normal, refracted);
+  const float reflectProb = totalReflection ? 1.f : fresnel(cosThetaI, cosThetaT, refIdx);
+  const uint32_t childSeed = fork_seed(ps.seed, ps.depth + 1);
+  v3 no, nd;
+  if (rnd(ps.seed) < reflectProb) { no = h.front; nd = reflect(ps.d, normal); }
+  else { no = h.back; nd = refracted; }
+  ps.thr = ps.thr * tint;
+  cnt<CNT>(ct.bounceRays);
+  bounce(sc, ps, no, nd, childSeed);
+}
+
+// Hit attributes of the nearest primitive (Geometry.cu:30-37, 81-86, 134-157)
+PT_HD void hit_attributes(const SceneView& sc, const PathState& ps, const Trav& tv, HitAttr& h) {
+  const float t = tv.tbest;
+  if (tv.bestPrim < sc.nSpheres) {
+    const DevSphere s = sc.spheres[tv.bestPrim];
+    const v3 p = ray_at(ps.o, ps.d, t);
+    h.geoNormal = normalize(p - s.center);
+    h.shadingNormal = h.geoNormal;
+    h.front = p; h.back = p;
+    h.mat = sc.sphereMat[tv.bestPrim];
+  } else if (tv.bestPrim < sc.nSpheres + sc.nQuads) {
+    const DevQuad* q = sc.quads + (tv.bestPrim - sc.nSpheres);
+    const v3 n = xyz(q->plane);
+    h.geoNormal = n; h.shadingNormal = n;
+    h.front = ray_at(ps.o, ps.d, t); h.back = h.front;
+    h.mat = q->mat;
+  } else {
+    const Tri48* tp = sc.tris + tv.bestTri;
+    const TriShade* sp = sc.triShade + tv.bestTri;
+    const v3 p0 = tp->p0, e0 = tp->e0, e1 = tp->e1;
+    h.mat = tp->mat;
+    h.geoNormal = normalize(cross(e1, e0));
+    if (sp->hasNormals) {
+      const v3 n0 = sp->n0, n1 = sp->n1, n2 = sp->n2;
+      h.shadingNormal = normalize((n1 * tv.beta + n2 * tv.gamma) + n0 * (1.f - tv.beta - tv.gamma));
+    } else {
+      h.shadingNormal = h.geoNormal;
+    }
+    refine_hitpoint(ray_at(ps.o, ps.d, t), ps.d, h.geoNormal, p0, h.back, h.front);
+  }
+}
+
+// The ray in flight has finished: run miss / closest-hit (radiance) or fold the shadow
+// result into the radiance (shadow).
+template <bool CNT>
+PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counters& ct) {
+  if (ps.kind == RK_SHADOW) {                                   // Material.cu:193-201
+    if (ps.pendInv != 0.f && length(tv.att) != 0.0f) {
+      const v3 c = (ps.pendW * tv.att) * ps.pendInv;
+      ps.rad = ps.rad + ps.thr * c;
+    }
+    ps.light++;
+    ps.mode = M_LIGHTS;
+    return;
+  }
+  if (tv.bestPrim < 0) {                                        // staticMiss, miss.cu:10-12
+    ps.rad = ps.rad + ps.thr * sc.bg;
+    end_sample(ps);
+    return;
+  }
+  cnt<CNT>(ct.closestHits);
+  HitAttr h;
+  hit_attributes(sc, ps, tv, h);
+  const DevMaterial& m = sc.mats[h.mat];
+  if (m.kind == MAT_LIGHT) {                                    // light, Material.cu:238-240
+    ps.rad = ps.rad + ps.thr * m.emission;
+    end_sample(ps);
+    return;
+  }
+  // Material.cu:29,50,73,119: depth cap -> absorbColor (0,0,0).  The second half of that test,
+  // length(payload.color) < rayMinIntensity, is dead in the reference: every payload starts
+  // at (1,1,1).
+  if (ps.depth > sc.maxDepth) { end_sample(ps); return; }
+
+  if (m.kind == MAT_LAMBERTIAN) {                               // Material.cu:28-43
+    const v3 no = ray_at(ps.o, ps.d, tv.tbest);
+    const v3 nd = normalize(h.geoNormal + rand_in_unit_sphere(ps.seed));
+    const uint32_t childSeed = fork_seed(ps.seed, ps.depth + 1);
+    ps.thr = ps.thr * m.albedo;
+    cnt<CNT>(ct.bounceRays);
+    bounce(sc, ps, no, nd, childSeed);
+  } else if (m.kind == MAT_METAL) {                             // Material.cu:49-66
+    const v3 no = ray_at(ps.o, ps.d, tv.tbest);
+    const v3 nd = normalize(reflect(ps.d, h.geoNormal) + rand_in_unit_sphere(ps.seed) * m.fuzz);
+    const uint32_t childSeed = fork_seed(ps.seed, ps.depth + 1);
+    ps.thr = ps.thr * m.albedo;
+    cnt<CNT>(ct.bounceRays);
+    bounce(sc, ps, no, nd, childSeed);
+  } else if (m.kind == MAT_GLASS) {                             // Material.cu:72-110
+    glass_body<CNT>(sc, ps, m.refIdx, m.albedo, h, ct);
+  } else {                                                      // disney, Material.cu:118-223
+    if (m.brdfType == BRDF_GLASS) { glass_body<CNT>(sc, ps, 1.45f, m.color, h, ct); return; }
+    ps.N = faceforward(h.shadingNormal, -ps.d, h.geoNormal);
+    ps.V = -ps.d;
+    ps.mat = h.mat;
+    ps.o = h.front;                 // every shadow ray and the bounce start at frontHitPoint
+    ps.rad = ps.rad + ps.thr * m.emission;
+    ps.light = 0;
+    ps.mode = M_LIGHTS;
+  }
+}
+
+// Disney next-event estimation loop + BRDF bounce (Material.cu:170-221).  Runs until the
+// lane owns a ray again (shadow ray towards light `ps.light`, or the bounce) or the sample ends.
+template <bool CNT>
+PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
+  const DevMaterial& m = sc.mats[ps.mat];
+  while (ps.light < sc.nLights) {
+    const DevLight* lt = sc.lights + ps.light;
+    cnt<CNT>(ct.lightLoads);
+    v3 pointOnLight, normalOnLight;
+    if (lt->shape == LIGHT_SPHERE) {
+      pointOnLight = lt->position + rand_in_unit_sphere(ps.seed) * lt->radius;
+      normalOnLight = normalize(pointOnLight - lt->position);
+    } else {
+      const float r1 = rnd(ps.seed); const float r2 = rnd(ps.seed);
+      pointOnLight = (lt->position + lt->u * r1) + lt->v * r2;
+      normalOnLight = normalize(lt->normal);
+    }
+    v3 L = pointOnLight - ps.o;
+    const float lightDst = length(L);
+    L = normalize(L);
+    if (dot(L, ps.N) > 0.f && dot(L, normalOnLight) < 0.f) {
+      const v3 H = normalize(L + ps.V);
+      const float lightPdf = lightDst * lightDst / lt->area / dot(normalOnLight, -L);
+      const float objPdf = disney_pdf(m, ps.N, L, H);
+      if (lightPdf > 0 && objPdf > 0) {
+        const v3 brdf = disney_eval(m, ps.N, L, ps.V, H);
+        ps.pendW = (brdf * powerHeuristic(lightPdf, objPdf)) * lt->emission;
+        ps.pendInv = 1.0f / fmaxf_(0.001f, lightPdf);
+      } else {
+        ps.pendW = mk3(0.f, 0.f, 0.f); ps.pendInv = 0.f;
+      }
+      ps.d = L; ps.tmin = sc.epsT; ps.tmax = lightDst - sc.epsT; ps.kind = RK_SHADOW;
+      ps.mode = M_TRACE;
+      cnt<CNT>(ct.shadowRays);
+      return;
+    }
+    ps.light++;
+  }
+  v3 L, H;
+  disney_sample(ps.seed, m, ps.N, ps.V, L, H);
+  if (dot(ps.N, L) > 0.0f && dot(ps.N, ps.V) > 0.0f) {
+    const uint32_t childSeed = fork_seed(ps.seed, ps.depth + 1);
+    const float pdf = disney_pdf(m, ps.N, L, H);
+    cnt<CNT>(ct.bounceRays);
+    if (pdf > 0) {
+      const v3 brdf = disney_eval(m, ps.N, L, ps.V, H);
+      ps.thr = (ps.thr * brdf) * (1.0f / pdf);
+      bounce(sc, ps, ps.o, L, childSeed);
+      return;
+    }
+  }
+  end_sample(ps);
+}
+
+}  // namespace pt

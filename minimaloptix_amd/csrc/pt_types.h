@@ -1,0 +1,109 @@
+// pt_types.h -- device-resident scene layout for the megakernel (HBM layout; DESIGN.md "Data layout").
+//
+// Everything the traversal loop touches is 16-byte aligned and sized so that one
+// record = a whole number of dwordx4 loads:
+//   Node64  : 64 B  two-child BVH node (both child boxes + both child refs)  -> 4 x dwordx4
+//   Tri48   : 48 B  triangle record p0,e0,e1 (+ material / primitive id in .w) -> 3 x dwordx4
+//   TriShade: 48 B  the three vertex normals, fetched once per closest hit
+// Analytic primitives (spheres/quads, incl. light geometry) live in short brute-force
+// lists that are read with wave-uniform (scalar) loads.
+#pragma once
+#include "pt_math.h"
+
+namespace pt {
+
+// child reference encoding: ref >= 0 -> internal node index; ref < 0 -> leaf, ~ref = (firstTri << 3) | (count-1)
+constexpr int kMaxLeaf = 8;
+PT_HD int make_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
+PT_HD int leaf_first(int ref) { return (~ref) >> 3; }
+PT_HD int leaf_count(int ref) { return ((~ref) & 7) + 1; }
+constexpr int kTravDone = 0x7fffffff;   // traversal finished sentinel in Trav::node
+constexpr int kEmptyRef = 0x7ffffffe;   // "no triangles" root
+
+struct alignas(64) Node64 {
+  v4 a;   // lo0.x lo0.y lo0.z hi0.x
+  v4 b;   // hi0.y hi0.z lo1.x lo1.y
+  v4 c;   // lo1.z hi1.x hi1.y hi1.z
+  int c0, c1;      // child references
+  int pad0, pad1;
+};
+static_assert(sizeof(Node64) == 64, "Node64 must be 64 bytes");
+
+struct alignas(16) Tri48 {
+  v3 p0; int mat;        // material id of the face
+  v3 e0; int prim;       // e0 = p1-p0 ; prim = original face index (upload order)
+  v3 e1; int pad;        // e1 = p0-p2
+};
+static_assert(sizeof(Tri48) == 48, "Tri48 must be 48 bytes");
+
+struct alignas(16) TriShade {
+  v3 n0; int hasNormals;
+  v3 n1; int pad1;
+  v3 n2; int pad2;
+};
+static_assert(sizeof(TriShade) == 48, "TriShade must be 48 bytes");
+
+struct alignas(16) DevQuad {   // QuadParams (Structures.h:28) + material
+  v4 plane;
+  v3 v1; int mat;
+  v3 v2; int pad0;
+  v3 anchor; int pad1;
+};
+static_assert(sizeof(DevQuad) == 64, "DevQuad must be 64 bytes");
+
+struct alignas(16) DevSphere { v3 center; float radius; };   // + sphereMat[] side array
+static_assert(sizeof(DevSphere) == 16, "DevSphere must be 16 bytes");
+
+struct alignas(16) DevLight {  // LightParams (Structures.h:70)
+  v3 position; float area;
+  v3 normal;   float radius;
+  v3 emission; int shape;
+  v3 u; int pad0;
+  v3 v; int pad1;
+};
+static_assert(sizeof(DevLight) == 80, "DevLight must be 80 bytes");
+
+enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_GLASS = 2, MAT_DISNEY = 3, MAT_LIGHT = 4 };
+enum { BRDF_NORMAL = 0, BRDF_GLASS = 1 };
+enum { LIGHT_SPHERE = 0, LIGHT_QUAD = 1 };
+
+// Material record: program parameters + the Disney constants that depend on the
+// material only (disney.h:49-77 evaluates them per call; they are pure functions of
+// DisneyParams, so they are evaluated once at upload with the same formulas -- AC6).
+struct alignas(16) DevMaterial {
+  int kind; int brdfType; float fuzz; float refIdx;
+  v3 albedo;   float metallic;
+  v3 emission; float roughness;
+  v3 color;    float subsurface;
+  // derived (valid for kind == MAT_DISNEY, untextured)
+  v3 Cdlin;    float sheen;          // srgb2lin(color)
+  v3 Cspec0;   float clearcoat;      // lerp(specular*.08*lerp(1,Ctint,specularTint), Cdlin, metallic)
+  v3 Csheen;   float oneMinusMetallic;
+  float diffuseRatio;                // .5*(1-metallic)
+  float specAlpha;                   // max(.001, roughness)
+  float ccAlpha;                     // lerp(.1,.001,clearcoatGloss)
+  float ccRatio;                     // 1/(1+clearcoat)
+  float ax, ay;                      // max(.001, roughness^2/aspect), max(.001, roughness^2*aspect)
+  float ccA2m1;                      // ccAlpha^2 - 1
+  float ccPiLogA2;                   // M_PIf * logf(ccAlpha^2)
+};
+static_assert(sizeof(DevMaterial) == 144, "DevMaterial layout");
+
+struct Cam { v3 origin, horizontal, vertical, scrLowerLeftCorner, u, v; float lensRadius; };
+
+// Everything a launch needs, passed by value as the kernel argument (scalar registers).
+struct SceneView {
+  int width, height;
+  int maxDepth; float minIntensity; float epsT;
+  v3 bg;
+  Cam cam;
+  int nSpheres; const DevSphere* spheres; const int* sphereMat;
+  int nQuads;   const DevQuad* quads;
+  int nLights;  const DevLight* lights;
+  int nMaterials; const DevMaterial* mats;
+  int anyDisneyAnalytic;          // any sphere/quad carries a Disney material (shadow any-hit applies)
+  int nTris; int rootRef;         // rootRef: node index, leaf ref or kEmptyRef
+  const Node64* nodes; const Tri48* tris; const TriShade* triShade;
+};
+
+}  // namespace pt

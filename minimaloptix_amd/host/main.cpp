@@ -1,0 +1,68 @@
+// moptix_render -- headless replacement of the reference's Qt application (main.cpp:4-10 +
+// MinimalOptiX ctor :9-33): picks a scene id, calls renderScene() and saves the canvas.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "minimal_optix.h"
+
+static void usage() {
+  fprintf(stderr,
+          "usage: moptix_render [--scene spheres|coffee|cornell_quads|random_spheres|random_spheres_256|dining_standin|million_standin|<file scene>]\n"
+          "                     [--spp N] [--width W] [--height H] [--seed S] [--scenes DIR/] [--out PREFIX] [--outdir DIR]\n"
+          "                     [--autosave] [--device D] [--random-seeds] [--strict-missing]\n");
+}
+
+int main(int argc, char** argv) {
+  std::string scene = "spheres", prefix = "frame", scenes = "scenes/", outdir = ".";
+  unsigned spp = 32, width = 1920, height = 1080, seed = 0;
+  int device = 0; bool autosave = false, randomSeeds = false, strict = false;
+  for (int i = 1; i < argc; i++) {
+    auto need = [&](const char* n) { if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", n); exit(2); } return argv[++i]; };
+    if (!strcmp(argv[i], "--scene")) scene = need("--scene");
+    else if (!strcmp(argv[i], "--spp")) spp = (unsigned)atoi(need("--spp"));
+    else if (!strcmp(argv[i], "--width")) width = (unsigned)atoi(need("--width"));
+    else if (!strcmp(argv[i], "--height")) height = (unsigned)atoi(need("--height"));
+    else if (!strcmp(argv[i], "--seed")) seed = (unsigned)strtoul(need("--seed"), nullptr, 0);
+    else if (!strcmp(argv[i], "--scenes")) scenes = need("--scenes");
+    else if (!strcmp(argv[i], "--out")) prefix = need("--out");
+    else if (!strcmp(argv[i], "--outdir")) outdir = need("--outdir");
+    else if (!strcmp(argv[i], "--device")) device = atoi(need("--device"));
+    else if (!strcmp(argv[i], "--autosave")) autosave = true;
+    else if (!strcmp(argv[i], "--random-seeds")) randomSeeds = true;
+    else if (!strcmp(argv[i], "--strict-missing")) strict = true;
+    else { usage(); return 2; }
+  }
+  try {
+    MinimalOptiX app(device);
+    app.fixedWidth = width; app.fixedHeight = height; app.nSuperSampling = spp;
+    app.baseSeed = seed; app.reproducibleSeeds = !randomSeeds; app.skipMissingMeshes = !strict;
+    app.baseSceneFolder = scenes; app.outputDir = outdir;
+    app.setupContext();
+    if (scene == "spheres") app.sceneId = MinimalOptiX::SCENE_SPHERES;
+    else if (scene == "coffee") app.sceneId = MinimalOptiX::SCENE_COFFEE;
+    else if (scene == "bedroom") app.sceneId = MinimalOptiX::SCENE_BEDROOM;
+    else if (scene == "diningroom") app.sceneId = MinimalOptiX::SCENE_DININGROOM;
+    else if (scene == "stormtrooper") app.sceneId = MinimalOptiX::SCENE_STORMTROOPER;
+    else if (scene == "spaceship") app.sceneId = MinimalOptiX::SCENE_SPACESHIP;
+    else if (scene == "cornell") app.sceneId = MinimalOptiX::SCENE_CORNELL;
+    else if (scene == "hyperion") app.sceneId = MinimalOptiX::SCENE_HYPERION;
+    else if (scene == "dragon") app.sceneId = MinimalOptiX::SCENE_DRAGON;
+    else if (scene == "random_spheres_256") app.sceneId = MinimalOptiX::SCENE_SPHERES_VIDEO;
+    else if (scene == "random_spheres") app.sceneId = MinimalOptiX::SCENE_RANDOM_SPHERES_500;
+    else if (scene == "cornell_quads") app.sceneId = MinimalOptiX::SCENE_CORNELL_QUADS;
+    else if (scene == "dining_standin") app.sceneId = MinimalOptiX::SCENE_DINING_STANDIN;
+    else if (scene == "million_standin") app.sceneId = MinimalOptiX::SCENE_MILLION_STANDIN;
+    else { usage(); return 2; }
+    app.renderScene(autosave, prefix);
+    if (!autosave) app.saveCurrentFrame(false, prefix);
+    fprintf(stderr, "render %.3f ms (device), BVH build %.3f ms, %u nodes, depth %u\n", app.lastRenderMs,
+            app.lastAccel.buildMs, app.lastAccel.nNodes, app.lastAccel.treeDepth);
+  } catch (const std::exception& e) {
+    fprintf(stderr, "moptix_render: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,122 @@
+#include "minimal_optix.h"
+
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <stdexcept>
+
+#include "../csrc/pt_rng.h"
+#include "image_io.h"
+
+using namespace moptix;
+
+MinimalOptiX::MinimalOptiX(int device) {
+  int rc = moptix_create(&context, device);
+  if (rc != MOPTIX_OK) throw std::runtime_error(std::string("moptix_create: ") + moptix_last_error(nullptr));
+  setupContext();
+}
+
+MinimalOptiX::~MinimalOptiX() { if (context) moptix_destroy(context); }
+
+void MinimalOptiX::check(int rc, const char* what) {
+  if (rc != MOPTIX_OK) throw std::runtime_error(std::string(what) + ": " + moptix_last_error(context));
+}
+
+// MinimalOptiX.cpp:130-152.  Ray types, entry points and the OptiX stack size have no
+// equivalent (the megakernel is iterative); the context variables travel in moptix_params
+// together with the camera and are pushed by setupScene().
+void MinimalOptiX::setupContext() {
+  canvas.assign((size_t)fixedWidth * fixedHeight * 3, 0);
+}
+
+// utils_host.cpp:118-122
+int MinimalOptiX::randSeed() {
+  if (reproducibleSeeds) return (int)pt::tea16(launchCounter++, baseSeed);
+  static auto engine = std::minstd_rand(std::random_device{}());
+  static auto randGen = std::uniform_real_distribution<float>(-1.f, 1.f);
+  return int(randGen(engine) * (float)std::numeric_limits<int>::max());
+}
+
+// MinimalOptiX.cpp:154-357
+void MinimalOptiX::setupScene() {
+  aabb.invalidate();
+  switch (sceneId) {
+    case SCENE_SPHERES: buildSpheresScene(scene, fixedWidth, fixedHeight); break;
+    case SCENE_COFFEE: setupScene("coffee"); return;
+    case SCENE_BEDROOM: setupScene("bedroom"); return;
+    case SCENE_DININGROOM: setupScene("diningroom"); return;
+    case SCENE_STORMTROOPER: setupScene("stormtrooper"); return;
+    case SCENE_SPACESHIP: setupScene("spaceship"); return;
+    case SCENE_CORNELL: setupScene("cornell"); return;
+    case SCENE_HYPERION: setupScene("hyperion"); return;
+    case SCENE_DRAGON: setupScene("dragon"); return;
+    case SCENE_SPHERES_VIDEO: buildRandomSpheresScene(scene, 256, fixedWidth, fixedHeight); break;   // :355
+    case SCENE_CORNELL_QUADS: buildCornellQuadsScene(scene, fixedWidth, fixedHeight); break;
+    case SCENE_RANDOM_SPHERES_500: buildRandomSpheresScene(scene, 497, fixedWidth, fixedHeight); break;
+    case SCENE_DINING_STANDIN: buildDiningStandInScene(scene, baseSceneFolder, 6, fixedWidth, fixedHeight); break;
+    case SCENE_MILLION_STANDIN: buildProceduralMillionScene(scene, 1000000, fixedWidth, fixedHeight); break;
+  }
+  scene.params.rayMaxDepth = rayMaxDepth; scene.params.rayMinIntensity = rayMinIntensity; scene.params.rayEpsilonT = rayEpsilonT;
+  aabb = scene.aabb; nVertices = scene.nVertices; nFaces = scene.nFaces;
+  check(upload(scene, context), "upload scene");
+}
+
+// MinimalOptiX.cpp:359-538 (+ the camera placement of :258-353)
+void MinimalOptiX::setupScene(const char* sceneName) {
+  buildFileScene(scene, baseSceneFolder, sceneName, fixedWidth, fixedHeight, skipMissingMeshes);
+  scene.params.rayMaxDepth = rayMaxDepth; scene.params.rayMinIntensity = rayMinIntensity; scene.params.rayEpsilonT = rayEpsilonT;
+  aabb = scene.aabb; nVertices = scene.nVertices; nFaces = scene.nFaces;
+  if (verbose) for (const std::string& w : scene.warnings) fprintf(stderr, "[MinimalOptiX] %s\n", w.c_str());
+  check(upload(scene, context), "upload scene");
+}
+
+// MinimalOptiX.cpp:540-560
+void MinimalOptiX::renderScene(bool autoSave, std::string fileNamePrefix) {
+  setupScene();
+  check(moptix_validate(context), "validate");                 // :542
+  moptix_get_accel_info(context, &lastAccel);
+  if (canvas.size() != (size_t)fixedWidth * fixedHeight * 3) canvas.assign((size_t)fixedWidth * fixedHeight * 3, 0);
+  moptix_kernel_time(context, nullptr, nullptr, 1);
+  std::vector<int32_t> seeds(nSuperSampling);
+  for (uint i = 0; i < nSuperSampling; ++i) seeds[i] = randSeed();   // :545 one seed per launch
+  uint checkpoint = 1;
+  uint done = 0;
+  while (done < nSuperSampling) {
+    // the reference launches once per sample (:546); the launches between two snapshots are
+    // fused into one kernel -- per pixel the samples are still added in launch order.
+    uint upto = nSuperSampling;
+    if (autoSave) { while (checkpoint <= done) checkpoint *= 2; upto = std::min(checkpoint, nSuperSampling); }
+    check(moptix_render(context, seeds.data() + done, (int32_t)(upto - done)), "render");
+    done = upto;
+    if (autoSave && done == checkpoint) {                       // :547-553
+      updateContent((float)done, false);
+      saveCurrentFrame(false, fileNamePrefix + "_" + std::to_string(done));
+    }
+  }
+  updateContent((float)nSuperSampling, true);                   // :555
+  if (autoSave) saveCurrentFrame(false, fileNamePrefix);        // :556-558
+  uint64_t n = 0;
+  moptix_kernel_time(context, &lastRenderMs, &n, 0);
+  if (verbose) fprintf(stderr, "vertices: %zu faces: %zu\n", nVertices, nFaces);   // :559
+}
+
+// MinimalOptiX.cpp:43-66 (normalise, clamp, flip rows, optionally clear) -- done on the device
+void MinimalOptiX::updateContent(float nAccumulation, bool clearBuffer) {
+  check(moptix_resolve_rgb8(context, nAccumulation, clearBuffer ? 1 : 0, canvas.data()), "resolve");
+}
+
+// MinimalOptiX.cpp:68-84
+void MinimalOptiX::saveCurrentFrame(bool popUpDialog, std::string fileNamePrefix) {
+  (void)popUpDialog;
+  std::string fileName = outputDir + "/" + (fileNamePrefix.empty() ? std::string("frame") : fileNamePrefix) + ".png";
+  if (!writePNG(fileName, canvas.data(), fixedWidth, fixedHeight)) throw std::runtime_error("cannot write " + fileName);
+  if (verbose) fprintf(stderr, "Image saved to %s\n", fileName.c_str());
+}
+
+// MinimalOptiX.cpp:86-110, restricted to the scenes whose assets exist
+void MinimalOptiX::imageDemo() {
+  nSuperSampling = 4096u;
+  sceneId = SCENE_COFFEE;
+  renderScene(true, "coffee");
+}

@@ -1,0 +1,834 @@
+/*
+ * pt_oracle.c -- CPU ORACLE (test infrastructure only; see pt_oracle.h header).
+ *
+ * Structure deliberately follows the reference: a *recursive* closest-hit
+ * evaluation, one function per OptiX program, brute-force lists for analytic
+ * primitives and an independent median-split BVH for triangles.  The HIP
+ * product path is organised completely differently (iterative, LBVH, LDS
+ * stack); agreement between the two is the parity evidence.
+ *
+ * Every function cites the reference file:line it restates
+ * (paths relative to /root/reference/MinimalOptiX/).
+ */
+#include "pt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ math -- */
+typedef struct { float x, y, z; } f3;
+
+static inline f3 mk3(float x, float y, float z) { f3 r = { x, y, z }; return r; }
+static inline f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+static inline void st3(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline f3 scl3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+static inline f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+static inline f3 adds3(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
+/* AC3: optix float3/float multiplies by the reciprocal */
+static inline f3 divs3(f3 a, float s) { float inv = 1.0f / s; return scl3(a, inv); }
+/* AC1 */
+static inline float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+/* AC2 */
+static inline f3 cross3(f3 a, f3 b) {
+  return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline float len3(f3 a) { return sqrtf(dot3(a, a)); }
+static inline f3 norm3(f3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return scl3(a, inv); }
+/* AC7 */
+static inline f3 ray_at(f3 o, f3 d, float t) { return mk3(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z)); }
+static inline float lerpf(float a, float b, float t) { return a + t * (b - a); }          /* A1 lerp */
+static inline f3 lerp3(f3 a, f3 b, float t) { return add3(a, scl3(sub3(b, a), t)); }
+static inline float clampf(float x, float lo, float hi) { return fmaxf(lo, fminf(x, hi)); }
+static inline float sqr(float x) { return x * x; }                                          /* utils_device.h:145 */
+/* AC5 */
+static inline float sin_ac(float x) { return (float)sin((double)x); }
+static inline float cos_ac(float x) { return (float)cos((double)x); }
+
+#define ORC_PI 3.14159265358979323846f  /* M_PIf */
+#define ORC_RT_DEFAULT_MAX 1e27f
+
+/* A1: reflect / faceforward / refract */
+static inline f3 reflect3(f3 i, f3 n) { return sub3(i, scl3(scl3(n, 2.0f), dot3(n, i))); }
+static inline f3 faceforward3(f3 n, f3 i, f3 nref) { return scl3(n, copysignf(1.0f, dot3(i, nref))); }
+static int refract3(f3* r, f3 i, f3 n, float ior) {
+  f3 nn = n;
+  float negNdotV = dot3(i, nn);
+  float eta;
+  if (negNdotV > 0.0f) { eta = ior; nn = neg3(n); negNdotV = -negNdotV; }
+  else { eta = 1.0f / ior; }
+  const float k = 1.0f - eta * eta * (1.0f - negNdotV * negNdotV);
+  if (k < 0.0f) { *r = mk3(0.f, 0.f, 0.f); return 0; }
+  *r = norm3(sub3(scl3(i, eta), scl3(nn, eta * negNdotV + sqrtf(k))));
+  return 1;
+}
+
+/* A1: Onb */
+typedef struct { f3 tangent, binormal, normal; } Onb;
+static Onb onb_make(f3 n) {
+  Onb o; o.normal = n;
+  if (fabsf(n.x) > fabsf(n.z)) o.binormal = mk3(-n.y, n.x, 0.f);
+  else                         o.binormal = mk3(0.f, -n.z, n.y);
+  o.binormal = norm3(o.binormal);
+  o.tangent = cross3(o.binormal, o.normal);
+  return o;
+}
+static inline f3 onb_inverse(const Onb* o, f3 p) {
+  return add3(add3(scl3(o->tangent, p.x), scl3(o->binormal, p.y)), scl3(o->normal, p.z));
+}
+
+/* ------------------------------------------------------------------- RNG -- */
+/* utils_device.h:8-22 tea<16> */
+uint32_t orc_tea16(uint32_t val0, uint32_t val1) {
+  uint32_t v0 = val0, v1 = val1, s0 = 0;
+  for (unsigned n = 0; n < 16; n++) {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+  }
+  return v0;
+}
+/* utils_device.h:24-29 */
+uint32_t orc_lcg(int32_t* seed) {
+  uint32_t s = (uint32_t)*seed;
+  s = 1664525u * s + 1013904223u;
+  *seed = (int32_t)s;
+  return s & 0x00FFFFFFu;
+}
+/* utils_device.h:32-34 */
+float orc_rand(int32_t* seed) { return (float)orc_lcg(seed) / (float)0x01000000; }
+/* launchSeed(i) = (int)tea<16>(i, baseSeed) */
+int32_t orc_launch_seed(uint32_t i, uint32_t baseSeed) { return (int32_t)orc_tea16(i, baseSeed); }
+
+/* utils_device.h:36-43 */
+static f3 rand_in_unit_sphere(int32_t* seed) {
+  f3 res;
+  do {
+    float a = orc_rand(seed), b = orc_rand(seed), c = orc_rand(seed);
+    res = sub3(scl3(mk3(a, b, c), 2.0f), mk3(1.f, 1.f, 1.f));
+  } while (len3(res) >= 1.0f);
+  return res;
+}
+/* utils_device.h:45-52 */
+static f3 rand_in_unit_disk(int32_t* seed) {
+  f3 res;
+  do {
+    float a = orc_rand(seed), b = orc_rand(seed);
+    res = sub3(scl3(mk3(a, b, 0.f), 2.0f), mk3(1.f, 1.f, 0.f));
+  } while (len3(res) >= 1.0f);
+  return res;
+}
+
+/* --------------------------------------------------------- host helpers -- */
+/* utils_host.cpp:77-99 */
+void orc_set_cam_params(const float from[3], const float at[3], const float upv[3],
+                        float vFoV, float aspect, float aperture, float focus, OrcCam* cam) {
+  static const float pi = 3.141592653589793238462643383279502884f;
+  f3 lookFrom = ld3(from), lookAt = ld3(at), up = ld3(upv);
+  float theta = vFoV * pi / 180;
+  float halfHeight = tanf(theta / 2);   /* `tan(float)` resolves to the float overload in C++ */
+  float halfWidth = aspect * halfHeight;
+  f3 w = norm3(sub3(lookFrom, lookAt));
+  f3 u = norm3(cross3(up, w));
+  f3 v = cross3(w, u);
+  f3 ll = sub3(sub3(sub3(lookFrom, scl3(u, focus * halfWidth)), scl3(v, focus * halfHeight)), scl3(w, focus));
+  f3 horizontal = scl3(u, 2 * focus * halfWidth);
+  f3 vertical = scl3(v, 2 * focus * halfHeight);
+  st3(cam->origin, lookFrom); st3(cam->horizontal, horizontal); st3(cam->vertical, vertical);
+  st3(cam->scrLowerLeftCorner, ll); st3(cam->u, u); st3(cam->v, v);
+  cam->lensRadius = aperture / 2;
+}
+/* utils_host.cpp:67-75 */
+void orc_set_quad_params(const float anchor[3], const float v1a[3], const float v2a[3], OrcQuad* q) {
+  f3 a = ld3(anchor), v1 = ld3(v1a), v2 = ld3(v2a);
+  f3 normal = norm3(cross3(v2, v1));
+  float d = dot3(normal, a);
+  q->plane[0] = normal.x; q->plane[1] = normal.y; q->plane[2] = normal.z; q->plane[3] = d;
+  st3(q->v1, divs3(v1, dot3(v1, v1)));
+  st3(q->v2, divs3(v2, dot3(v2, v2)));
+  st3(q->anchor, a);
+}
+/* utils_host.cpp:101-116 */
+void orc_init_disney(OrcMaterial* m) {
+  memset(m, 0, sizeof(*m));
+  m->kind = ORC_DISNEY;
+  m->color[0] = m->color[1] = m->color[2] = 1.0f;
+  m->metallic = 0.0f; m->subsurface = 0.0f; m->specular = 0.5f; m->roughness = 0.5f;
+  m->specularTint = 0.0f; m->anisotropic = 0.0f; m->sheen = 0.0f; m->sheenTint = 0.5f;
+  m->clearcoat = 0.0f; m->clearcoatGloss = 1.0f; m->brdfType = ORC_BRDF_NORMAL; m->albedoID = 0;
+}
+
+/* -------------------------------------------------- utils_device helpers -- */
+/* utils_device.h:63-67 */
+static float fresnel(float cosThetaI, float cosThetaT, float refIdx) {
+  float rs = (cosThetaI - cosThetaT * refIdx) / (cosThetaI + refIdx * cosThetaT);
+  float rp = (cosThetaI * refIdx - cosThetaT) / (cosThetaI * refIdx + cosThetaT);
+  return 0.5f * (rs * rs + rp * rp);
+}
+static inline int32_t f2i(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+static inline float i2f(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+/* utils_device.h:82-104 */
+static float offset1(float h, float n) {
+  const float epsilon = 1.0e-4f;
+  const float offs = 4096.0f * 2.0f;
+  if ((f2i(h) & 0x7fffffff) < f2i(epsilon)) return h + epsilon * n;
+  return i2f(f2i(h) + (int32_t)(copysignf(offs, h) * n));
+}
+static f3 offset_pt(f3 p, f3 n) { return mk3(offset1(p.x, n.x), offset1(p.y, n.y), offset1(p.z, n.z)); }
+void orc_offset(const float p[3], const float n[3], float out[3]) { st3(out, offset_pt(ld3(p), ld3(n))); }
+/* utils_device.h:72-79 */
+static float intersect_plane(f3 origin, f3 direction, f3 normal, f3 point) {
+  return -(dot3(normal, sub3(origin, point))) / dot3(normal, direction);
+}
+/* utils_device.h:108-128 */
+static void refine_hitpoint(f3 original, f3 direction, f3 normal, f3 p, f3* back, f3* front) {
+  float refined_t = intersect_plane(original, direction, normal, p);
+  f3 refined = ray_at(original, direction, refined_t);
+  if (dot3(direction, normal) > 0.0f) { *back = offset_pt(refined, normal); *front = offset_pt(refined, neg3(normal)); }
+  else                                { *back = offset_pt(refined, neg3(normal)); *front = offset_pt(refined, normal); }
+}
+/* utils_device.h:130-167 */
+static float GTR1(float NDotH, float a) {
+  if (a >= 1.f) return 1.f / ORC_PI;
+  float a2 = a * a;
+  float t = 1.f + (a2 - 1.f) * NDotH * NDotH;
+  return (a2 - 1.0f) / (ORC_PI * logf(a2) * t);   /* AC6: logf of a per-material constant */
+}
+static float GTR2(float NDotH, float a) {
+  float a2 = a * a;
+  float t = 1.f + (a2 - 1.f) * NDotH * NDotH;
+  return a2 / (ORC_PI * t * t);
+}
+static float GTR2Aniso(float NdotH, float HdotX, float HdotY, float ax, float ay) {
+  return 1 / (ORC_PI * ax * ay * sqr(sqr(HdotX / ax) + sqr(HdotY / ay) + NdotH * NdotH));
+}
+static float schlickFresnel(float u) {
+  float m = clampf(1.f - u, 0.f, 1.f);
+  float m2 = m * m;
+  return m2 * m2 * m;
+}
+static float smithGGgx(float NdotV, float alphaG) {
+  float a = alphaG * alphaG;
+  float b = NdotV * NdotV;
+  return 1.f / (NdotV + sqrtf(a + b - a * b));
+}
+static float smithGGgxAniso(float NdotV, float VdotX, float VdotY, float ax, float ay) {
+  return 1.0f / (NdotV + sqrtf(sqr(VdotX * ax) + sqr(VdotY * ay) + sqr(NdotV)));
+}
+/* utils_device.h:173-175; AC6 */
+static f3 srgb2lin(f3 v) { return mk3(powf(v.x, 2.2f), powf(v.y, 2.2f), powf(v.z, 2.2f)); }
+/* utils_device.h:182-185 */
+static float powerHeuristic(float a, float b) { float t = a * a; return t / (b * b + t); }
+
+/* -------------------------------------------------------------- disney.h -- */
+/* A1 cosine_sample_hemisphere */
+static f3 cosine_sample_hemisphere(float u1, float u2) {
+  const float r = sqrtf(u1);
+  const float phi = (2.0f * ORC_PI) * u2;
+  f3 p;
+  p.x = r * cos_ac(phi);
+  p.y = r * sin_ac(phi);
+  p.z = sqrtf(fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
+  return p;
+}
+/* disney.h:9-30 */
+static void disney_sample(int32_t* seed, const OrcMaterial* m, f3 N, f3 V, f3* L, f3* H) {
+  float diffuseRatio = 0.5f * (1.0f - m->metallic);
+  Onb onb = onb_make(N);
+  if (orc_rand(seed) < diffuseRatio) {
+    float u1 = orc_rand(seed), u2 = orc_rand(seed);
+    f3 l = cosine_sample_hemisphere(u1, u2);
+    l = onb_inverse(&onb, l);
+    *L = norm3(l);
+    *H = norm3(add3(*L, V));
+  } else {
+    float a = fmaxf(0.001f, m->roughness);
+    float phi = orc_rand(seed) * 2.0f * ORC_PI;
+    float random = orc_rand(seed);
+    float cosTheta = sqrtf((1.f - random) / (1.0f + (a * a - 1.f) * random));
+    float sinTheta = sqrtf(1.0f - (cosTheta * cosTheta));
+    float sinPhi = sin_ac(phi);
+    float cosPhi = cos_ac(phi);
+    f3 h = mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+    h = onb_inverse(&onb, h);
+    *L = norm3(sub3(scl3(h, 2.0f * dot3(V, h)), V));
+    *H = norm3(h);
+  }
+}
+/* disney.h:32-46 */
+static float disney_pdf(const OrcMaterial* m, f3 N, f3 L, f3 V, f3 H) {
+  (void)V;
+  float diffuseRatio = 0.5f * (1.0f - m->metallic);
+  float specularAlpha = fmaxf(0.001f, m->roughness);
+  float clearcoatAlpha = lerpf(0.1f, 0.001f, m->clearcoatGloss);
+  float specularRatio = 1.f - diffuseRatio;
+  float cosTheta = fabsf(dot3(N, H));
+  float pdfGTR1 = GTR1(cosTheta, clearcoatAlpha) * cosTheta;
+  float pdfGTR2 = GTR2(cosTheta, specularAlpha) * cosTheta;
+  float ratio = 1.0f / (1.0f + m->clearcoat);
+  float pdfH = lerpf(pdfGTR1, pdfGTR2, ratio);
+  float pdfL = pdfH / (4.0f * fabsf(dot3(L, H)));
+  float pdfDiff = fabsf(dot3(N, L)) / ORC_PI;
+  return diffuseRatio * pdfDiff + specularRatio * pdfL;
+}
+/* disney.h:48-91 */
+static f3 disney_eval(const OrcMaterial* m, f3 baseColor, f3 N, f3 L, f3 V, f3 H) {
+  Onb onb = onb_make(N);
+  float NdotL = dot3(N, L), NdotV = dot3(N, V), NdotH = dot3(N, H), LdotH = dot3(L, H);
+  f3 Cdlin = srgb2lin(baseColor);
+  float Cdlum = dot3(Cdlin, mk3(0.3f, 0.6f, 0.1f));
+  f3 Ctint = Cdlum > 0.f ? divs3(Cdlin, Cdlum) : mk3(1.f, 1.f, 1.f);
+  f3 one = mk3(1.f, 1.f, 1.f);
+  f3 Cspec0 = lerp3(scl3(lerp3(one, Ctint, m->specularTint), m->specular * 0.08f), Cdlin, m->metallic);
+  f3 Csheen = lerp3(one, Ctint, m->sheenTint);
+
+  float FL = schlickFresnel(NdotL);
+  float FV = schlickFresnel(NdotV);
+  float Fd90 = 0.5f + 2.f * LdotH * LdotH * m->roughness;
+  float Fd = lerpf(1.f, Fd90, FL) * lerpf(1.f, Fd90, FV);
+
+  float Fss90 = LdotH * LdotH * m->roughness;
+  float Fss = lerpf(1.0f, Fss90, FL) * lerpf(1.0f, Fss90, FV);
+  float ss = 1.25f * (Fss * (1.f / (NdotL + NdotV) - 0.5f) + 0.5f);
+
+  float aspect = sqrtf(1 - m->anisotropic * 0.9f);
+  float ax = fmaxf(.001f, sqr(m->roughness) / aspect);
+  float ay = fmaxf(.001f, sqr(m->roughness) * aspect);
+  f3 X = norm3(onb.tangent);
+  f3 Y = norm3(cross3(N, X));
+  float Ds = GTR2Aniso(NdotH, dot3(H, X), dot3(H, Y), ax, ay);
+  float FH = schlickFresnel(LdotH);
+  f3 Fs = lerp3(Cspec0, one, FH);
+  float Gs = smithGGgxAniso(NdotL, dot3(L, X), dot3(L, Y), ax, ay) *
+             smithGGgxAniso(NdotV, dot3(V, X), dot3(V, Y), ax, ay);
+  f3 Fsheen = scl3(Csheen, FH * m->sheen);
+  float Dr = GTR1(NdotH, lerpf(0.1f, 0.001f, m->clearcoatGloss));
+  float Fr = lerpf(0.04f, 1.f, FH);
+  float Gr = smithGGgx(NdotL, 0.25f) * smithGGgx(NdotV, 0.25f);
+  /* ((1/pi)*lerp(Fd,ss,subsurface)*Cdlin + Fsheen)*(1-metallic) + Gs*Fs*Ds + 0.25*clearcoat*Gr*Fr*Dr */
+  f3 diffuse = scl3(add3(scl3(Cdlin, (1.0f / ORC_PI) * lerpf(Fd, ss, m->subsurface)), Fsheen), 1.0f - m->metallic);
+  f3 spec = scl3(scl3(Fs, Gs), Ds);
+  float cc = 0.25f * m->clearcoat * Gr * Fr * Dr;
+  return adds3(add3(diffuse, spec), cc);
+}
+
+float orc_disney_pdf(const OrcMaterial* m, const float N[3], const float L[3], const float V[3], const float H[3]) {
+  return disney_pdf(m, ld3(N), ld3(L), ld3(V), ld3(H));
+}
+void orc_disney_eval(const OrcMaterial* m, const float base[3], const float N[3], const float L[3],
+                     const float V[3], const float H[3], float out[3]) {
+  st3(out, disney_eval(m, ld3(base), ld3(N), ld3(L), ld3(V), ld3(H)));
+}
+void orc_disney_sample(int32_t* seed, const OrcMaterial* m, const float N[3], const float V[3], float L[3], float H[3]) {
+  f3 l, h; disney_sample(seed, m, ld3(N), ld3(V), &l, &h); st3(L, l); st3(H, h);
+}
+int orc_refract(float r[3], const float i[3], const float n[3], float ior) {
+  f3 rr; int ok = refract3(&rr, ld3(i), ld3(n), ior); st3(r, rr); return ok;
+}
+
+/* --------------------------------------------------------- intersection -- */
+/* A1 intersect_triangle (== intersect_triangle_branchless) */
+static int tri_test(f3 o, f3 d, float tmin, float tmax, f3 p0, f3 p1, f3 p2,
+                    f3* n, float* t, float* beta, float* gamma) {
+  const f3 e0 = sub3(p1, p0);
+  const f3 e1 = sub3(p0, p2);
+  *n = cross3(e1, e0);
+  const f3 e2 = scl3(sub3(p0, o), 1.0f / dot3(*n, d));
+  const f3 i = cross3(d, e2);
+  *beta = dot3(i, e1);
+  *gamma = dot3(i, e0);
+  *t = dot3(*n, e2);
+  return (*t < tmax) & (*t > tmin) & (*beta >= 0.0f) & (*gamma >= 0.0f) & (*beta + *gamma <= 1.0f);
+}
+int orc_intersect_triangle(const float o[3], const float d[3], float tmin, float tmax,
+                           const float p0[3], const float p1[3], const float p2[3],
+                           float n[3], float* t, float* beta, float* gamma) {
+  f3 nn; int r = tri_test(ld3(o), ld3(d), tmin, tmax, ld3(p0), ld3(p1), ld3(p2), &nn, t, beta, gamma);
+  st3(n, nn); return r;
+}
+
+/* Independent triangle BVH (median split, <=4 tris per leaf). Boxes are padded
+ * and the slab test is slack so that culling can never reject a triangle the
+ * exact test would accept: results equal brute force (tests check this). */
+typedef struct { float bmin[3], bmax[3]; int32_t left, right, first, count; } BNode;
+typedef struct { BNode* nodes; int32_t nNodes; int32_t* order; } TriBVH;
+
+static const float* g_centroids;   /* qsort context (build is single threaded) */
+static int g_axis;
+static int cmp_centroid(const void* a, const void* b) {
+  float ca = g_centroids[3 * (*(const int32_t*)a) + g_axis], cb = g_centroids[3 * (*(const int32_t*)b) + g_axis];
+  if (ca < cb) return -1; if (ca > cb) return 1;
+  int32_t ia = *(const int32_t*)a, ib = *(const int32_t*)b;
+  return (ia > ib) - (ia < ib);
+}
+static int32_t bvh_build_rec(TriBVH* bvh, const float* tmin3, const float* tmax3, int32_t first, int32_t count) {
+  int32_t id = bvh->nNodes++;
+  BNode* nd = &bvh->nodes[id];
+  float cmin[3] = { 1e37f, 1e37f, 1e37f }, cmax[3] = { -1e37f, -1e37f, -1e37f };
+  for (int k = 0; k < 3; k++) { nd->bmin[k] = 1e37f; nd->bmax[k] = -1e37f; }
+  for (int32_t i = first; i < first + count; i++) {
+    int32_t t = bvh->order[i];
+    for (int k = 0; k < 3; k++) {
+      nd->bmin[k] = fminf(nd->bmin[k], tmin3[3 * t + k]);
+      nd->bmax[k] = fmaxf(nd->bmax[k], tmax3[3 * t + k]);
+      float c = g_centroids[3 * t + k];
+      cmin[k] = fminf(cmin[k], c); cmax[k] = fmaxf(cmax[k], c);
+    }
+  }
+  nd->first = first; nd->count = count; nd->left = nd->right = -1;
+  if (count <= 4) return id;
+  int axis = 0; float ext = cmax[0] - cmin[0];
+  for (int k = 1; k < 3; k++) if (cmax[k] - cmin[k] > ext) { ext = cmax[k] - cmin[k]; axis = k; }
+  g_axis = axis;
+  qsort(bvh->order + first, (size_t)count, sizeof(int32_t), cmp_centroid);
+  int32_t half = count / 2;
+  int32_t l = bvh_build_rec(bvh, tmin3, tmax3, first, half);
+  int32_t r = bvh_build_rec(bvh, tmin3, tmax3, first + half, count - half);
+  nd = &bvh->nodes[id];
+  nd->left = l; nd->right = r; nd->count = 0;
+  return id;
+}
+static TriBVH* bvh_build(const OrcScene* sc) {
+  int32_t n = sc->nFaces;
+  TriBVH* bvh = (TriBVH*)calloc(1, sizeof(TriBVH));
+  bvh->nodes = (BNode*)malloc(sizeof(BNode) * (size_t)(2 * n + 1));
+  bvh->order = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  float* tmin3 = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+  float* tmax3 = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+  float* cen = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+  float smin[3] = { 1e37f, 1e37f, 1e37f }, smax[3] = { -1e37f, -1e37f, -1e37f };
+  for (int32_t t = 0; t < n; t++) {
+    bvh->order[t] = t;
+    for (int k = 0; k < 3; k++) {
+      float a = sc->positions[3 * sc->vIdx[3 * t + 0] + k];
+      float b = sc->positions[3 * sc->vIdx[3 * t + 1] + k];
+      float c = sc->positions[3 * sc->vIdx[3 * t + 2] + k];
+      tmin3[3 * t + k] = fminf(fminf(a, b), c);
+      tmax3[3 * t + k] = fmaxf(fmaxf(a, b), c);
+      cen[3 * t + k] = (tmin3[3 * t + k] + tmax3[3 * t + k]) * 0.5f;
+      smin[k] = fminf(smin[k], tmin3[3 * t + k]); smax[k] = fmaxf(smax[k], tmax3[3 * t + k]);
+    }
+  }
+  /* pad every triangle box by a scene-relative slack */
+  float diag = fmaxf(fmaxf(smax[0] - smin[0], smax[1] - smin[1]), smax[2] - smin[2]);
+  float pad = 1e-5f * diag + 1e-30f;
+  for (int32_t i = 0; i < 3 * n; i++) { tmin3[i] -= pad + 1e-6f * fabsf(tmin3[i]); tmax3[i] += pad + 1e-6f * fabsf(tmax3[i]); }
+  g_centroids = cen;
+  if (n > 0) bvh_build_rec(bvh, tmin3, tmax3, 0, n);
+  free(tmin3); free(tmax3); free(cen);
+  return bvh;
+}
+static void bvh_free(TriBVH* b) { if (!b) return; free(b->nodes); free(b->order); free(b); }
+
+typedef struct {
+  float t; int32_t prim; int32_t mat;
+  f3 geoNormal, shadingNormal, frontHitPoint, backHitPoint;
+} Hit;
+
+typedef struct {
+  const OrcScene* sc;
+  const TriBVH* bvh;
+  OrcStats st;
+} Ctx;
+
+/* rtPotentialIntersection restated with a deterministic equal-t rule
+ * (SURVEY A2 divergence D5): nearer t wins; at exactly equal t the lower
+ * primitive id wins.  Primitive ids: spheres, then quads, then triangles. */
+static inline int potential(float t, int32_t prim, float tmin, float tbest, int32_t bestPrim) {
+  return ((t > tmin) & (t < tbest)) | ((t == tbest) & (bestPrim >= 0) & (prim < bestPrim));
+}
+
+/* Geometry.cu:18-55 (root selection only; attributes are filled for the winner) */
+static int sphere_roots(const OrcSphere* s, f3 o, f3 d, float* t1, float* t2) {
+  f3 oc = sub3(o, ld3(s->center));
+  float b = dot3(d, oc);
+  float c = dot3(oc, oc) - s->radius * s->radius;
+  float disc = b * b - c;
+  if (disc < 0) return 0;
+  float sq = sqrtf(disc);
+  *t1 = -b - sq; *t2 = -b + sq;
+  return 1;
+}
+/* Geometry.cu:70-91 */
+static int quad_test(const OrcQuad* q, f3 o, f3 d, float tmin, float tmax, float* tOut) {
+  f3 n = mk3(q->plane[0], q->plane[1], q->plane[2]);
+  float dt = dot3(d, n);
+  float t = (q->plane[3] - dot3(n, o)) / dt;
+  if (t > tmin && t < tmax) {
+    f3 p = ray_at(o, d, t);
+    f3 vi = sub3(p, ld3(q->anchor));
+    float a1 = dot3(ld3(q->v1), vi);
+    if (a1 >= 0 && a1 <= 1) {
+      float a2 = dot3(ld3(q->v2), vi);
+      if (a2 >= 0 && a2 <= 1) { *tOut = t; return 1; }
+    }
+  }
+  return 0;
+}
+static inline f3 vert(const OrcScene* sc, int32_t i) { return ld3(sc->positions + 3 * (size_t)i); }
+
+static inline int box_hit(const BNode* nd, f3 o, f3 inv, float tmin, float tmax) {
+  float t0x = (nd->bmin[0] - o.x) * inv.x, t1x = (nd->bmax[0] - o.x) * inv.x;
+  float t0y = (nd->bmin[1] - o.y) * inv.y, t1y = (nd->bmax[1] - o.y) * inv.y;
+  float t0z = (nd->bmin[2] - o.z) * inv.z, t1z = (nd->bmax[2] - o.z) * inv.z;
+  float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+  float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+  return tn <= tf * 1.0000005f + 1e-30f;
+}
+
+/* rtTrace nearest-hit search (A1), ray type radiance.  Returns 1 on hit. */
+static int find_closest(Ctx* cx, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
+  const OrcScene* sc = cx->sc;
+  float best = tmax; int32_t bestPrim = -1; int bestRoot = 0;
+  for (int32_t i = 0; i < sc->nSpheres; i++) {
+    float t1, t2;
+    if (!sphere_roots(&sc->spheres[i], o, d, &t1, &t2)) continue;
+    if (potential(t1, i, tmin, best, bestPrim)) { best = t1; bestPrim = i; bestRoot = 1; }
+    else if (potential(t2, i, tmin, best, bestPrim)) { best = t2; bestPrim = i; bestRoot = 2; }
+  }
+  for (int32_t i = 0; i < sc->nQuads; i++) {
+    float t; int32_t id = sc->nSpheres + i;
+    /* Geometry.cu:74 tests against ray.tmax then rtPotentialIntersection */
+    if (quad_test(&sc->quads[i], o, d, tmin, tmax, &t) && potential(t, id, tmin, best, bestPrim)) { best = t; bestPrim = id; }
+  }
+  const int32_t triBase = sc->nSpheres + sc->nQuads;
+  float bBeta = 0, bGamma = 0; f3 bN = mk3(0, 0, 0);
+  if (sc->nFaces > 0) {
+    if (sc->bruteForceTris || !cx->bvh) {
+      for (int32_t f = 0; f < sc->nFaces; f++) {
+        f3 n; float t, be, ga;
+        if (tri_test(o, d, tmin, tmax, vert(sc, sc->vIdx[3 * f]), vert(sc, sc->vIdx[3 * f + 1]), vert(sc, sc->vIdx[3 * f + 2]), &n, &t, &be, &ga)
+            && potential(t, triBase + f, tmin, best, bestPrim)) { best = t; bestPrim = triBase + f; bBeta = be; bGamma = ga; bN = n; }
+      }
+    } else {
+      const TriBVH* bvh = cx->bvh;
+      f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+      int32_t stack[128]; int sp = 0; stack[sp++] = 0;
+      while (sp > 0) {
+        const BNode* nd = &bvh->nodes[stack[--sp]];
+        if (!box_hit(nd, o, inv, tmin, best)) continue;
+        if (nd->left < 0) {
+          for (int32_t k = nd->first; k < nd->first + nd->count; k++) {
+            int32_t f = bvh->order[k];
+            f3 n; float t, be, ga;
+            if (tri_test(o, d, tmin, tmax, vert(sc, sc->vIdx[3 * f]), vert(sc, sc->vIdx[3 * f + 1]), vert(sc, sc->vIdx[3 * f + 2]), &n, &t, &be, &ga)
+                && potential(t, triBase + f, tmin, best, bestPrim)) { best = t; bestPrim = triBase + f; bBeta = be; bGamma = ga; bN = n; }
+          }
+        } else { stack[sp++] = nd->left; stack[sp++] = nd->right; }
+      }
+    }
+  }
+  if (bestPrim < 0) return 0;
+  hit->t = best; hit->prim = bestPrim;
+  if (bestPrim < sc->nSpheres) {                       /* Geometry.cu:30-53 */
+    const OrcSphere* s = &sc->spheres[bestPrim];
+    (void)bestRoot;
+    f3 p = ray_at(o, d, best);
+    hit->geoNormal = norm3(sub3(p, ld3(s->center)));
+    hit->shadingNormal = hit->geoNormal;
+    hit->frontHitPoint = p; hit->backHitPoint = p;
+    hit->mat = s->mat;
+  } else if (bestPrim < triBase) {                     /* Geometry.cu:81-86 */
+    const OrcQuad* q = &sc->quads[bestPrim - sc->nSpheres];
+    f3 n = mk3(q->plane[0], q->plane[1], q->plane[2]);
+    hit->geoNormal = n; hit->shadingNormal = n;
+    hit->frontHitPoint = ray_at(o, d, best); hit->backHitPoint = hit->frontHitPoint;
+    hit->mat = q->mat;
+  } else {                                             /* Geometry.cu:134-157 */
+    int32_t f = bestPrim - triBase;
+    hit->geoNormal = norm3(bN);
+    const int32_t* ni = sc->nIdx + 3 * (size_t)f;
+    if (sc->nNorms == 0 || ni[0] < 0 || ni[1] < 0 || ni[2] < 0) {
+      hit->shadingNormal = hit->geoNormal;
+    } else {
+      f3 n0 = ld3(sc->normals + 3 * (size_t)ni[0]), n1 = ld3(sc->normals + 3 * (size_t)ni[1]), n2 = ld3(sc->normals + 3 * (size_t)ni[2]);
+      hit->shadingNormal = norm3(add3(add3(scl3(n1, bBeta), scl3(n2, bGamma)), scl3(n0, 1.f - bBeta - bGamma)));
+    }
+    refine_hitpoint(ray_at(o, d, best), d, hit->geoNormal, vert(sc, sc->vIdx[3 * f]), &hit->backHitPoint, &hit->frontHitPoint);
+    hit->mat = sc->faceMat[f];
+  }
+  return 1;
+}
+
+int orc_closest_hit(const OrcScene* sc, const float org[3], const float dir[3], float tmin, float tmax, float* tHit) {
+  Ctx cx; memset(&cx, 0, sizeof(cx)); cx.sc = sc;
+  TriBVH* bvh = (sc->nFaces > 0 && !sc->bruteForceTris) ? bvh_build(sc) : NULL;
+  cx.bvh = bvh;
+  Hit h; int r = find_closest(&cx, ld3(org), ld3(dir), tmin, tmax, &h);
+  bvh_free(bvh);
+  if (!r) return -1;
+  if (tHit) *tHit = h.t;
+  return h.prim;
+}
+
+/* Shadow ray (ray type 1): Material.cu:187-193 + disneyAnyHit :225-232, with the
+ * deterministic definition of SURVEY A2: an opaque Disney surface anywhere in
+ * (tmin,tmax) zeroes the attenuation; every glass Disney surface crossed
+ * multiplies by its (untextured) colour; instances without a shadow any-hit
+ * program (lights, lambertian/metal/glass spheres and quads) do not occlude. */
+static inline int shadow_apply(const OrcScene* sc, int32_t mat, f3* att) {
+  const OrcMaterial* m = &sc->materials[mat];
+  if (m->kind != ORC_DISNEY) return 0;
+  if (m->brdfType == ORC_BRDF_GLASS) { *att = mul3(*att, ld3(m->color)); return 0; }
+  *att = mk3(0.f, 0.f, 0.f);
+  return 1; /* rtTerminateRay */
+}
+static f3 shadow_attenuation(Ctx* cx, f3 o, f3 d, float tmin, float tmax) {
+  const OrcScene* sc = cx->sc;
+  f3 att = mk3(1.f, 1.f, 1.f);
+  for (int32_t i = 0; i < sc->nSpheres; i++) {
+    float t1, t2;
+    if (sc->materials[sc->spheres[i].mat].kind != ORC_DISNEY) continue;
+    if (!sphere_roots(&sc->spheres[i], o, d, &t1, &t2)) continue;
+    if ((t1 > tmin && t1 < tmax) || (t2 > tmin && t2 < tmax)) if (shadow_apply(sc, sc->spheres[i].mat, &att)) return att;
+  }
+  for (int32_t i = 0; i < sc->nQuads; i++) {
+    float t;
+    if (sc->materials[sc->quads[i].mat].kind != ORC_DISNEY) continue;
+    if (quad_test(&sc->quads[i], o, d, tmin, tmax, &t)) if (shadow_apply(sc, sc->quads[i].mat, &att)) return att;
+  }
+  if (sc->nFaces > 0) {
+    if (sc->bruteForceTris || !cx->bvh) {
+      for (int32_t f = 0; f < sc->nFaces; f++) {
+        f3 n; float t, be, ga;
+        if (tri_test(o, d, tmin, tmax, vert(sc, sc->vIdx[3 * f]), vert(sc, sc->vIdx[3 * f + 1]), vert(sc, sc->vIdx[3 * f + 2]), &n, &t, &be, &ga))
+          if (shadow_apply(sc, sc->faceMat[f], &att)) return att;
+      }
+    } else {
+      const TriBVH* bvh = cx->bvh;
+      f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+      int32_t stack[128]; int sp = 0; stack[sp++] = 0;
+      while (sp > 0) {
+        const BNode* nd = &bvh->nodes[stack[--sp]];
+        if (!box_hit(nd, o, inv, tmin, tmax)) continue;
+        if (nd->left < 0) {
+          for (int32_t k = nd->first; k < nd->first + nd->count; k++) {
+            int32_t f = bvh->order[k];
+            f3 n; float t, be, ga;
+            if (tri_test(o, d, tmin, tmax, vert(sc, sc->vIdx[3 * f]), vert(sc, sc->vIdx[3 * f + 1]), vert(sc, sc->vIdx[3 * f + 2]), &n, &t, &be, &ga))
+              if (shadow_apply(sc, sc->faceMat[f], &att)) return att;
+          }
+        } else { stack[sp++] = nd->left; stack[sp++] = nd->right; }
+      }
+    }
+  }
+  return att;
+}
+
+/* ------------------------------------------------------- material programs -- */
+typedef struct { f3 color; int32_t depth; int32_t randSeed; } Payload;   /* Structures.h:5-10 */
+
+static void trace_radiance(Ctx* cx, f3 o, f3 d, float tmin, float tmax, Payload* pld);
+
+/* utils_device.h:192-198 folkPayload */
+static Payload fork_payload(const Payload* parent) {
+  Payload c; c.depth = parent->depth + 1; c.color = mk3(1.f, 1.f, 1.f);
+  c.randSeed = (int32_t)orc_tea16((uint32_t)parent->randSeed, (uint32_t)c.depth);
+  return c;
+}
+static inline int absorbed(const OrcScene* sc, const Payload* p) {   /* Material.cu:29,50,73,119 */
+  return (p->depth > sc->rayMaxDepth) || (len3(p->color) < sc->rayMinIntensity);
+}
+
+/* Material.cu:28-43 */
+static void prog_lambertian(Ctx* cx, const OrcMaterial* m, f3 o, f3 d, const Hit* h, Payload* p) {
+  if (absorbed(cx->sc, p)) { cx->st.depthCapped++; p->color = mk3(0.f, 0.f, 0.f); return; }
+  f3 no = ray_at(o, d, h->t);
+  f3 nd = norm3(add3(h->geoNormal, rand_in_unit_sphere(&p->randSeed)));
+  Payload c = fork_payload(p);
+  cx->st.bounceRays++;
+  trace_radiance(cx, no, nd, cx->sc->rayEpsilonT, ORC_RT_DEFAULT_MAX, &c);
+  p->color = mul3(c.color, ld3(m->albedo));
+}
+/* Material.cu:49-66 */
+static void prog_metal(Ctx* cx, const OrcMaterial* m, f3 o, f3 d, const Hit* h, Payload* p) {
+  if (absorbed(cx->sc, p)) { cx->st.depthCapped++; p->color = mk3(0.f, 0.f, 0.f); return; }
+  f3 no = ray_at(o, d, h->t);
+  f3 nd = norm3(add3(reflect3(d, h->geoNormal), scl3(rand_in_unit_sphere(&p->randSeed), m->fuzz)));
+  Payload c = fork_payload(p);
+  cx->st.bounceRays++;
+  trace_radiance(cx, no, nd, cx->sc->rayEpsilonT, ORC_RT_DEFAULT_MAX, &c);
+  p->color = mul3(ld3(m->albedo), c.color);
+}
+/* Material.cu:72-110 (glass) and :134-168 (disney GLASS branch) share this body */
+static void glass_body(Ctx* cx, float ior, f3 tint, f3 d, const Hit* h, Payload* p) {
+  f3 normal = h->shadingNormal;
+  float cosThetaI = -dot3(d, normal);
+  float refIdx;
+  if (cosThetaI > 0.f) { refIdx = ior; }
+  else { refIdx = 1.f / ior; cosThetaI = -cosThetaI; normal = neg3(normal); }
+  f3 refracted;
+  int totalReflection = !refract3(&refracted, d, normal, refIdx);
+  float cosThetaT = -dot3(normal, refracted);
+  float reflectProb = totalReflection ? 1.f : fresnel(cosThetaI, cosThetaT, refIdx);
+  Payload c = fork_payload(p);                  /* fork BEFORE the draw: Material.cu:100-101 */
+  f3 no, nd;
+  if (orc_rand(&p->randSeed) < reflectProb) { no = h->frontHitPoint; nd = reflect3(d, normal); }
+  else { no = h->backHitPoint; nd = refracted; }
+  cx->st.bounceRays++;
+  trace_radiance(cx, no, nd, cx->sc->rayEpsilonT, ORC_RT_DEFAULT_MAX, &c);
+  p->color = mul3(c.color, tint);
+}
+static void prog_glass(Ctx* cx, const OrcMaterial* m, f3 d, const Hit* h, Payload* p) {
+  if (absorbed(cx->sc, p)) { cx->st.depthCapped++; p->color = mk3(0.f, 0.f, 0.f); return; }
+  glass_body(cx, m->refIdx, ld3(m->albedo), d, h, p);
+}
+/* Material.cu:118-223 */
+static void prog_disney(Ctx* cx, const OrcMaterial* m, f3 d, const Hit* h, Payload* p) {
+  const OrcScene* sc = cx->sc;
+  if (absorbed(sc, p)) { cx->st.depthCapped++; p->color = mk3(0.f, 0.f, 0.f); return; }
+  f3 N = faceforward3(h->shadingNormal, neg3(d), h->geoNormal);
+  f3 V = neg3(d);
+  f3 L, H;
+  f3 baseColor = ld3(m->color);   /* albedoID == RT_TEXTURE_ID_NULL: textures are a "next" row */
+  if (m->brdfType == ORC_BRDF_GLASS) { glass_body(cx, 1.45f, baseColor, d, h, p); return; }
+
+  f3 direct = mk3(0.f, 0.f, 0.f);
+  for (int32_t i = 0; i < sc->nLights; ++i) {
+    const OrcLight* light = &sc->lights[i];
+    f3 pointOnLight, normalOnLight;
+    if (light->shape == ORC_LIGHT_SPHERE) {
+      pointOnLight = add3(ld3(light->position), scl3(rand_in_unit_sphere(&p->randSeed), light->radius));
+      normalOnLight = norm3(sub3(pointOnLight, ld3(light->position)));
+    } else {
+      float r1 = orc_rand(&p->randSeed); float r2 = orc_rand(&p->randSeed);
+      pointOnLight = add3(add3(ld3(light->position), scl3(ld3(light->u), r1)), scl3(ld3(light->v), r2));
+      normalOnLight = norm3(ld3(light->normal));
+    }
+    L = sub3(pointOnLight, h->frontHitPoint);
+    float lightDst = len3(L);
+    L = norm3(L);
+    if (dot3(L, N) > 0.f && dot3(L, normalOnLight) < 0.f) {
+      cx->st.shadowRays++;
+      f3 att = shadow_attenuation(cx, h->frontHitPoint, L, sc->rayEpsilonT, lightDst - sc->rayEpsilonT);
+      if (len3(att) != 0.0f) {
+        H = norm3(add3(L, V));
+        float lightPdf = lightDst * lightDst / light->area / dot3(normalOnLight, neg3(L));
+        float objPdf = disney_pdf(m, N, L, V, H);
+        if (lightPdf > 0 && objPdf > 0) {
+          f3 brdf = disney_eval(m, baseColor, N, L, V, H);
+          f3 c = divs3(mul3(mul3(scl3(brdf, powerHeuristic(lightPdf, objPdf)), ld3(light->emission)), att), fmaxf(0.001f, lightPdf));
+          direct = add3(direct, c);
+        }
+      }
+    }
+  }
+
+  f3 indirect = mk3(0.f, 0.f, 0.f);
+  disney_sample(&p->randSeed, m, N, V, &L, &H);
+  if (dot3(N, L) > 0.0f && dot3(N, V) > 0.0f) {
+    Payload c = fork_payload(p);
+    cx->st.bounceRays++;
+    trace_radiance(cx, h->frontHitPoint, L, sc->rayEpsilonT, ORC_RT_DEFAULT_MAX, &c);
+    float pdf = disney_pdf(m, N, L, V, H);
+    if (pdf > 0) {
+      f3 brdf = disney_eval(m, baseColor, N, L, V, H);
+      indirect = divs3(mul3(brdf, c.color), pdf);
+    }
+  }
+  p->color = add3(add3(indirect, direct), ld3(m->emission));
+}
+
+/* rtTrace for ray type 0: nearest hit -> closest-hit program; none -> miss.cu:10-12 */
+static void trace_radiance(Ctx* cx, f3 o, f3 d, float tmin, float tmax, Payload* pld) {
+  Hit h;
+  if (!find_closest(cx, o, d, tmin, tmax, &h)) {
+    cx->st.misses++;
+    pld->color = mul3(pld->color, ld3(cx->sc->bgColor));
+    return;
+  }
+  cx->st.closestHits++;
+  const OrcMaterial* m = &cx->sc->materials[h.mat];
+  switch (m->kind) {
+    case ORC_LAMBERTIAN: prog_lambertian(cx, m, o, d, &h, pld); break;
+    case ORC_METAL:      prog_metal(cx, m, o, d, &h, pld); break;
+    case ORC_GLASS:      prog_glass(cx, m, d, &h, pld); break;
+    case ORC_DISNEY:     prog_disney(cx, m, d, &h, pld); break;
+    case ORC_LIGHT:      pld->color = ld3(m->emission); break;   /* Material.cu:238-240 */
+    default: break;
+  }
+}
+
+void orc_trace_one(const OrcScene* sc, const float org[3], const float dir[3], int32_t seed, float outColor[3]) {
+  Ctx cx; memset(&cx, 0, sizeof(cx)); cx.sc = sc;
+  TriBVH* bvh = (sc->nFaces > 0 && !sc->bruteForceTris) ? bvh_build(sc) : NULL;
+  cx.bvh = bvh;
+  Payload p; p.depth = 1; p.randSeed = seed; p.color = mk3(1.f, 1.f, 1.f);
+  trace_radiance(&cx, ld3(org), ld3(dir), sc->rayEpsilonT, ORC_RT_DEFAULT_MAX, &p);
+  st3(outColor, p.color);
+  bvh_free(bvh);
+}
+
+/* Camera.cu:21-42 for one pixel and one launch seed */
+static f3 camera_sample(Ctx* cx, int32_t x, int32_t y, int32_t launchSeed) {
+  const OrcScene* sc = cx->sc;
+  const OrcCam* cam = &sc->cam;
+  Payload pld;
+  pld.depth = 1;
+  pld.randSeed = (int32_t)orc_tea16((uint32_t)y * (uint32_t)sc->width + (uint32_t)x, (uint32_t)launchSeed);
+  pld.color = mk3(1.f, 1.f, 1.f);
+  f3 randInLens = scl3(rand_in_unit_disk(&pld.randSeed), cam->lensRadius);
+  f3 offs = add3(scl3(ld3(cam->u), randInLens.x), scl3(ld3(cam->v), randInLens.y));
+  float r1 = orc_rand(&pld.randSeed); float r2 = orc_rand(&pld.randSeed);
+  float xyx = ((float)x + r1 - 0.5f) / (float)sc->width;
+  float xyy = ((float)y + r2 - 0.5f) / (float)sc->height;
+  f3 org = add3(ld3(cam->origin), offs);
+  f3 dir = norm3(sub3(sub3(add3(add3(ld3(cam->scrLowerLeftCorner), scl3(ld3(cam->horizontal), xyx)),
+                                 scl3(ld3(cam->vertical), xyy)), ld3(cam->origin)), offs));
+  cx->st.primaryRays++; cx->st.samples++;
+  trace_radiance(cx, org, dir, sc->rayEpsilonT, ORC_RT_DEFAULT_MAX, &pld);
+  return mk3(clampf(pld.color.x, 0.f, 1.f), clampf(pld.color.y, 0.f, 1.f), clampf(pld.color.z, 0.f, 1.f));
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+int orc_render(const OrcScene* sc, const int32_t* seeds, int nSeeds, float* accum,
+               int x0, int y0, int x1, int y1, int nThreads, OrcStats* stats) {
+  if (!sc || !accum || (!seeds && nSeeds > 0)) return -1;
+  if (x0 < 0 || y0 < 0 || x1 > sc->width || y1 > sc->height || x0 > x1 || y0 > y1) return -2;
+  for (int32_t f = 0; f < 3 * sc->nFaces; f++) if (sc->vIdx[f] < 0 || sc->vIdx[f] >= sc->nVerts) return -3;
+  TriBVH* bvh = (sc->nFaces > 0 && !sc->bruteForceTris) ? bvh_build(sc) : NULL;
+  OrcStats total; memset(&total, 0, sizeof(total));
+#ifdef _OPENMP
+  if (nThreads > 0) omp_set_num_threads(nThreads);
+#else
+  (void)nThreads;
+#endif
+  const int rows = y1 - y0;
+#pragma omp parallel
+  {
+    Ctx cx; memset(&cx, 0, sizeof(cx)); cx.sc = sc; cx.bvh = bvh;
+#pragma omp for schedule(dynamic, 1)
+    for (int r = 0; r < rows; r++) {
+      int y = y0 + r;
+      for (int x = x0; x < x1; x++) {
+        float* px = accum + 3 * ((size_t)y * (size_t)sc->width + (size_t)x);
+        for (int s = 0; s < nSeeds; s++) {      /* one launch per seed, in order (MinimalOptiX.cpp:544-546) */
+          f3 c = camera_sample(&cx, x, y, seeds[s]);
+          px[0] += c.x; px[1] += c.y; px[2] += c.z;   /* Camera.cu:41 */
+        }
+      }
+    }
+#pragma omp critical
+    {
+      total.primaryRays += cx.st.primaryRays; total.bounceRays += cx.st.bounceRays; total.shadowRays += cx.st.shadowRays;
+      total.samples += cx.st.samples; total.closestHits += cx.st.closestHits; total.misses += cx.st.misses;
+      total.depthCapped += cx.st.depthCapped;
+    }
+  }
+  bvh_free(bvh);
+  if (stats) *stats = total;
+  return 0;
+}

@@ -1,0 +1,235 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE.  Compiles the megakernel's per-lane code
+// (minimaloptix_amd/csrc/pt_*.h) for the host and runs it one pixel at a time, plus a
+// sequential mirror of the device LBVH build (same pt_lbvh.h primitives).  Used
+//   * here (no GPU) to check the flattened state machine + LBVH traversal against the
+//     recursive CPU oracle before any GPU time is spent, and
+//   * on the GPU box to compare the device-built BVH with this mirror word for word.
+// It is not part of the product: nothing under minimaloptix_amd/ builds or loads it.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../minimaloptix_amd/csrc/pt_path.h"
+#include "../../minimaloptix_amd/csrc/pt_lbvh.h"
+#include "../../minimaloptix_amd/csrc/pt_upload.h"
+
+using namespace pt;
+
+extern "C" {
+
+struct hostsim_scene {
+  moptix_params params;
+  int32_t nMaterials; const moptix_material* materials;
+  int32_t nSpheres; const moptix_sphere_params* spheres; const int32_t* sphereMat;
+  int32_t nQuads; const moptix_quad_params* quads; const int32_t* quadMat;
+  int32_t nLights; const moptix_light_params* lights;
+  int32_t nFaces;
+  const float* facePos;      // 9 floats per face: p0 p1 p2
+  const float* faceNrm;      // 9 floats per face (ignored where faceHasNrm == 0); may be NULL
+  const int32_t* faceHasNrm; // may be NULL
+  const int32_t* faceMat;
+};
+
+struct hostsim_bvh_out {      // caller-allocated: nodes >= max(1,nFaces-1)*64 B, tris nFaces*48 B
+  void* nodes; void* tris; int32_t* triPrim;
+  int32_t nNodes, rootRef, depth;
+};
+
+}  // extern "C"
+
+namespace {
+
+struct HostBVH {
+  std::vector<Node64> nodes; std::vector<Tri48> tris; std::vector<TriShade> shade;
+  int rootRef = kEmptyRef; int depth = 0;
+};
+
+static int subtree_depth(const std::vector<Node64>& nodes, int ref) {
+  if (ref < 0) return 0;
+  // iterative to be safe on deep LBVHs
+  int best = 0;
+  std::vector<std::pair<int, int>> st; st.push_back({ ref, 1 });
+  while (!st.empty()) {
+    auto [r, d] = st.back(); st.pop_back();
+    best = std::max(best, d);
+    if (nodes[r].c0 >= 0) st.push_back({ nodes[r].c0, d + 1 });
+    if (nodes[r].c1 >= 0) st.push_back({ nodes[r].c1, d + 1 });
+  }
+  return best;
+}
+
+static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
+  const int n = s.nFaces;
+  out.nodes.clear(); out.tris.clear(); out.shade.clear(); out.rootRef = kEmptyRef; out.depth = 0;
+  if (n <= 0) return;
+  std::vector<v3> lo(n), hi(n), cen(n);
+  v3 clo = mk3(1e37f, 1e37f, 1e37f), chi = mk3(-1e37f, -1e37f, -1e37f);
+  v3 slo = clo, shi = chi;
+  for (int f = 0; f < n; f++) {
+    const float* p = s.facePos + 9 * (size_t)f;
+    tri_bounds(mk3(p[0], p[1], p[2]), mk3(p[3], p[4], p[5]), mk3(p[6], p[7], p[8]), lo[f], hi[f]);
+    cen[f] = (lo[f] + hi[f]) * 0.5f;
+    clo = mk3(fminf_(clo.x, cen[f].x), fminf_(clo.y, cen[f].y), fminf_(clo.z, cen[f].z));
+    chi = mk3(fmaxf_(chi.x, cen[f].x), fmaxf_(chi.y, cen[f].y), fmaxf_(chi.z, cen[f].z));
+    slo = mk3(fminf_(slo.x, lo[f].x), fminf_(slo.y, lo[f].y), fminf_(slo.z, lo[f].z));
+    shi = mk3(fmaxf_(shi.x, hi[f].x), fmaxf_(shi.y, hi[f].y), fmaxf_(shi.z, hi[f].z));
+  }
+  const v3 invExt = mk3(inv_extent(clo.x, chi.x), inv_extent(clo.y, chi.y), inv_extent(clo.z, chi.z));
+  const float padAbs = 1e-5f * fmaxf_(fmaxf_(shi.x - slo.x, shi.y - slo.y), shi.z - slo.z) + 1e-30f;
+  std::vector<uint64_t> keys(n);
+  for (int f = 0; f < n; f++) keys[f] = ((uint64_t)morton30(cen[f], clo, invExt) << 32) | (uint32_t)f;
+  std::sort(keys.begin(), keys.end());
+
+  out.tris.resize(n); out.shade.resize(n);
+  std::vector<v3> llo(n), lhi(n);
+  for (int k = 0; k < n; k++) {
+    const int f = (int)(keys[k] & 0xffffffffu);
+    const float* p = s.facePos + 9 * (size_t)f;
+    const v3 p0 = mk3(p[0], p[1], p[2]), p1 = mk3(p[3], p[4], p[5]), p2 = mk3(p[6], p[7], p[8]);
+    Tri48 t; memset(&t, 0, sizeof(t));
+    t.p0 = p0; t.e0 = p1 - p0; t.e1 = p0 - p2; t.mat = s.faceMat[f]; t.prim = f;
+    out.tris[k] = t;
+    TriShade sh; memset(&sh, 0, sizeof(sh));
+    if (s.faceNrm && s.faceHasNrm && s.faceHasNrm[f]) {
+      const float* q = s.faceNrm + 9 * (size_t)f;
+      sh.n0 = mk3(q[0], q[1], q[2]); sh.n1 = mk3(q[3], q[4], q[5]); sh.n2 = mk3(q[6], q[7], q[8]); sh.hasNormals = 1;
+    }
+    out.shade[k] = sh;
+    llo[k] = mk3(pad_lo(lo[f].x, padAbs), pad_lo(lo[f].y, padAbs), pad_lo(lo[f].z, padAbs));
+    lhi[k] = mk3(pad_hi(hi[f].x, padAbs), pad_hi(hi[f].y, padAbs), pad_hi(hi[f].z, padAbs));
+  }
+  if (n <= leafSize) { out.rootRef = make_leaf_ref(0, n); return; }
+
+  const int ni = n - 1;
+  std::vector<KarrasNode> kn(ni);
+  std::vector<int> first(ni), last(ni);
+  for (int i = 0; i < ni; i++) { kn[i] = karras_node(keys.data(), n, i); first[i] = kn[i].first; last[i] = kn[i].last; }
+  // boxes of every Karras node = union of the leaf boxes in its range (what the device's
+  // bottom-up atomic pass produces; min/max are exact so the order does not matter)
+  std::vector<v3> ilo(ni), ihi(ni);
+  {
+    // process nodes by increasing range size so children are ready before parents
+    std::vector<int> order(ni);
+    for (int i = 0; i < ni; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return (last[a] - first[a]) < (last[b] - first[b]); });
+    auto clo_of = [&](int c) { return c < 0 ? llo[~c] : ilo[c]; };
+    auto chi_of = [&](int c) { return c < 0 ? lhi[~c] : ihi[c]; };
+    for (int i : order) {
+      const v3 a = clo_of(kn[i].left), b = clo_of(kn[i].right), c = chi_of(kn[i].left), d = chi_of(kn[i].right);
+      ilo[i] = mk3(fminf_(a.x, b.x), fminf_(a.y, b.y), fminf_(a.z, b.z));
+      ihi[i] = mk3(fmaxf_(c.x, d.x), fmaxf_(c.y, d.y), fmaxf_(c.z, d.z));
+    }
+  }
+  std::vector<int> newIndex(ni, -1);
+  int nKept = 0;
+  for (int i = 0; i < ni; i++) if (last[i] - first[i] + 1 > leafSize) newIndex[i] = nKept++;
+  out.nodes.resize(nKept);
+  auto box_of = [&](int child, v3& blo, v3& bhi) {
+    if (child < 0) { blo = llo[~child]; bhi = lhi[~child]; } else { blo = ilo[child]; bhi = ihi[child]; }
+  };
+  for (int i = 0; i < ni; i++) {
+    if (newIndex[i] < 0) continue;
+    Node64 nd; memset(&nd, 0, sizeof(nd));
+    v3 l0, h0, l1, h1;
+    box_of(kn[i].left, l0, h0); box_of(kn[i].right, l1, h1);
+    nd.a.x = l0.x; nd.a.y = l0.y; nd.a.z = l0.z; nd.a.w = h0.x;
+    nd.b.x = h0.y; nd.b.y = h0.z; nd.b.z = l1.x; nd.b.w = l1.y;
+    nd.c.x = l1.z; nd.c.y = h1.x; nd.c.z = h1.y; nd.c.w = h1.z;
+    nd.c0 = collapsed_ref(kn[i].left, first.data(), last.data(), newIndex.data(), leafSize);
+    nd.c1 = collapsed_ref(kn[i].right, first.data(), last.data(), newIndex.data(), leafSize);
+    out.nodes[newIndex[i]] = nd;
+  }
+  out.rootRef = 0;
+  out.depth = subtree_depth(out.nodes, 0);
+}
+
+struct LocalStack {
+  int data[256];
+  inline void store(int sp, int v) { data[sp] = v; }
+  inline int load(int sp) const { return data[sp]; }
+};
+
+struct HostScene {
+  std::vector<DevMaterial> mats; std::vector<DevSphere> spheres; std::vector<int> sphereMat;
+  std::vector<DevQuad> quads; std::vector<DevLight> lights; HostBVH bvh; SceneView view;
+};
+
+static void make_scene(const hostsim_scene& s, int leafSize, HostScene& hs) {
+  for (int i = 0; i < s.nMaterials; i++) hs.mats.push_back(make_dev_material(s.materials[i]));
+  for (int i = 0; i < s.nSpheres; i++) { hs.spheres.push_back(make_dev_sphere(s.spheres[i])); hs.sphereMat.push_back(s.sphereMat[i]); }
+  for (int i = 0; i < s.nQuads; i++) hs.quads.push_back(make_dev_quad(s.quads[i], s.quadMat[i]));
+  for (int i = 0; i < s.nLights; i++) hs.lights.push_back(make_dev_light(s.lights[i]));
+  build_lbvh(s, leafSize, hs.bvh);
+  SceneView& v = hs.view;
+  memset(&v, 0, sizeof(v));
+  v.width = (int)s.params.width; v.height = (int)s.params.height;
+  v.maxDepth = (int)s.params.rayMaxDepth; v.minIntensity = s.params.rayMinIntensity; v.epsT = s.params.rayEpsilonT;
+  v.bg = to_v3(s.params.bgColor); v.cam = make_cam(s.params.cam);
+  v.nSpheres = s.nSpheres; v.spheres = hs.spheres.data(); v.sphereMat = hs.sphereMat.data();
+  v.nQuads = s.nQuads; v.quads = hs.quads.data();
+  v.nLights = s.nLights; v.lights = hs.lights.data();
+  v.nMaterials = s.nMaterials; v.mats = hs.mats.data();
+  v.anyDisneyAnalytic = 0;
+  for (int i = 0; i < s.nSpheres; i++) if (hs.mats[s.sphereMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
+  for (int i = 0; i < s.nQuads; i++) if (hs.mats[s.quadMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
+  v.nTris = s.nFaces; v.rootRef = hs.bvh.rootRef;
+  v.nodes = hs.bvh.nodes.data(); v.tris = hs.bvh.tris.data(); v.triShade = hs.bvh.shade.data();
+}
+
+}  // namespace
+
+extern "C" {
+
+int hostsim_build_bvh(const hostsim_scene* s, int leafSize, hostsim_bvh_out* out) {
+  HostBVH b; build_lbvh(*s, leafSize, b);
+  out->nNodes = (int)b.nodes.size(); out->rootRef = b.rootRef; out->depth = b.depth;
+  if (out->nodes && !b.nodes.empty()) memcpy(out->nodes, b.nodes.data(), b.nodes.size() * sizeof(Node64));
+  if (out->tris && !b.tris.empty()) memcpy(out->tris, b.tris.data(), b.tris.size() * sizeof(Tri48));
+  if (out->triPrim) for (size_t i = 0; i < b.tris.size(); i++) out->triPrim[i] = b.tris[i].prim;
+  return 0;
+}
+
+// counters: samples, primary, bounce, shadow, nodeFetches, triTests, closestHits, lightLoads, analyticTests
+int hostsim_render(const hostsim_scene* s, int leafSize, const int32_t* seeds, int nSeeds, float* accum, uint64_t counters[9]) {
+  HostScene hs; make_scene(*s, leafSize, hs);
+  const SceneView& sc = hs.view;
+  uint64_t tot[9] = { 0 };
+  const int nPix = sc.width * sc.height;
+#pragma omp parallel
+  {
+    uint64_t loc[9] = { 0 };
+#pragma omp for schedule(dynamic, 64)
+    for (int pix = 0; pix < nPix; pix++) {
+      PathState ps; memset(&ps, 0, sizeof(ps));
+      Trav tv; memset(&tv, 0, sizeof(tv));
+      Counters ct; memset(&ct, 0, sizeof(ct));
+      LocalStack st;
+      ps.pixel = pix; ps.sample = 0;
+      ps.accum = mk3(accum[3 * pix], accum[3 * pix + 1], accum[3 * pix + 2]);
+      ps.mode = M_NEW_SAMPLE;
+      for (;;) {
+        if (ps.mode == M_NEW_SAMPLE) {
+          if (ps.sample >= nSeeds) break;
+          begin_sample<true>(sc, ps, seeds[ps.sample], ct);
+        } else if (ps.mode == M_TRACE) {
+          trav_begin<true>(sc, ps, tv, ct);
+          while (tv.node != kTravDone) trav_step<true>(sc, ps, tv, st, ct);
+          ps.mode = M_RESULT;
+        } else if (ps.mode == M_RESULT) {
+          on_result<true>(sc, ps, tv, ct);
+        } else if (ps.mode == M_LIGHTS) {
+          on_lights<true>(sc, ps, ct);
+        }
+      }
+      accum[3 * pix] = ps.accum.x; accum[3 * pix + 1] = ps.accum.y; accum[3 * pix + 2] = ps.accum.z;
+      loc[0] += ct.samples; loc[1] += ct.primaryRays; loc[2] += ct.bounceRays; loc[3] += ct.shadowRays;
+      loc[4] += ct.nodeFetches; loc[5] += ct.triTests; loc[6] += ct.closestHits; loc[7] += ct.lightLoads; loc[8] += ct.analyticTests;
+    }
+#pragma omp critical
+    for (int i = 0; i < 9; i++) tot[i] += loc[i];
+  }
+  if (counters) for (int i = 0; i < 9; i++) counters[i] = tot[i];
+  return 0;
+}
+
+}  // extern "C"
