@@ -105,6 +105,8 @@ typedef struct moptix_stats {
   uint64_t analyticTests;        /* sphere/quad records tested (brute-force lists)        */
   uint64_t traversalSteps;       /* wave-level loop iterations (x64 lanes = lane slots)   */
   uint64_t activeLaneSteps;      /* lanes doing useful work summed over those iterations  */
+  uint64_t shadeBatches;         /* variant 1: shading/regeneration batches run            */
+  uint64_t shadeBatchLanes;      /* variant 1: slots processed by those batches            */
 } moptix_stats;
 
 typedef struct moptix_accel_info {
@@ -171,8 +173,11 @@ int moptix_render_counted(moptix_context ctx, const int32_t* seeds, int32_t nSee
  * tiles t (raster order) with t % nRanks == rank.  Default (0,1) = whole frame. */
 int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
 
-/* tuning knobs: "exit_threshold" (lanes), "leaf_size" (1..8, before build_accel),
- * "blocks_per_cu", "kernel_variant".  Unknown names -> MOPTIX_ERR_INVALID. */
+/* tuning knobs: "kernel_variant" (0 = one path per lane, 1 = path pool with wave-level
+ * compaction), "leaf_size" (1..8, before build_accel), "blocks_per_cu", "exit_threshold"
+ * (variant 0), "pool_slots" (128|192|256), "refill_lanes", "starve_lanes" (variant 1),
+ * "sample_buffer_mb" (budget of the per-sample buffer; larger batches run in passes).
+ * Unknown names -> MOPTIX_ERR_INVALID. */
 int moptix_set_option(moptix_context ctx, const char* name, int32_t value);
 int moptix_get_option(moptix_context ctx, const char* name, int32_t* value);
 
@@ -188,8 +193,11 @@ int moptix_accum_bind(moptix_context ctx, void* devPtr);
 int moptix_resolve_rgb8(moptix_context ctx, float nAccumulation, int clearBuffer, uint8_t* dstHost);
 
 /* ---- measurement ----------------------------------------------------------- */
-/* device time (HIP events on the launch stream) of render kernels since the last reset */
+/* device time (HIP events on the launch stream) of the trace kernel -- the dominant kernel --
+ * and the number of its launches since the last reset */
 int moptix_kernel_time(moptix_context ctx, double* totalMs, uint64_t* nLaunches, int reset);
+/* device time of the ordered sample reductions that followed those launches */
+int moptix_reduce_time(moptix_context ctx, double* totalMs);
 
 /* debug/validation: copy the built BVH to host (nodes: nNodes*64 B, tris: nTriangles*48 B,
  * triPrimIds: nTriangles int32 = original face index of each record). Any pointer may be NULL. */

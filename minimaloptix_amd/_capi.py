@@ -74,7 +74,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("samples", "primaryRays", "bounceRays", "shadowRays", "nodeFetches", "triTests", "closestHits",
-                 "lightLoads", "analyticTests", "traversalSteps", "activeLaneSteps")]
+                 "lightLoads", "analyticTests", "traversalSteps", "activeLaneSteps", "shadeBatches", "shadeBatchLanes")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -107,7 +107,7 @@ DEVICE_SYMBOLS = [
     "moptix_validate", "moptix_launch", "moptix_render", "moptix_render_async", "moptix_sync",
     "moptix_render_counted", "moptix_set_partition", "moptix_set_option", "moptix_get_option",
     "moptix_accum_read", "moptix_accum_clear", "moptix_accum_device_ptr", "moptix_accum_bind",
-    "moptix_resolve_rgb8", "moptix_kernel_time", "moptix_debug_read_accel", "moptix_debug_trace",
+    "moptix_resolve_rgb8", "moptix_kernel_time", "moptix_reduce_time", "moptix_debug_read_accel", "moptix_debug_trace",
 ]
 HOST_SYMBOLS = [
     "mohost_last_error", "mohost_scene_build", "mohost_scene_free", "mohost_scene_get_sizes",
@@ -162,6 +162,7 @@ def device_lib():
         L.moptix_accum_bind.argtypes = [vp, vp]
         L.moptix_resolve_rgb8.argtypes = [vp, C.c_float, C.c_int, C.POINTER(C.c_uint8)]
         L.moptix_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        L.moptix_reduce_time.argtypes = [vp, C.POINTER(C.c_double)]
         L.moptix_debug_read_accel.argtypes = [vp, vp, vp, i32p]
         L.moptix_debug_trace.argtypes = [vp, f32p, i32, f32p, i32p]
         _dev = L

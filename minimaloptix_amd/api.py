@@ -250,6 +250,11 @@ class Context:
         self._chk(self._L.moptix_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
 
+    def reduce_time(self):
+        ms = C.c_double()
+        self._chk(self._L.moptix_reduce_time(self._h, C.byref(ms)))
+        return ms.value
+
     def debug_read_accel(self):
         a = self.accel_info()
         nodes = np.zeros((max(1, a.nNodes), 16), np.uint32)

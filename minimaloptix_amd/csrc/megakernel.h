@@ -9,16 +9,48 @@ struct LaunchArgs {
   SceneView scene;
   const int* seeds; int nSeeds;     // launch seeds, one sample per pixel each (device memory)
   float* accum;                     // accuBuffer: float3 W*H, row 0 = bottom
+  float* sampleBuf;                 // per-sample results: float3 [nSeeds][nItems]
   int* workCounter;                 // global work-item counter (zeroed before the launch)
-  int nWork;                        // work items of this rank = local tiles * 64
+  int nItems;                       // pixels-slots of this rank = local tiles * 64
+  int nWork;                        // work items = nSeeds * nItems, item k = (sample k / nItems, slot k % nItems)
   int tilesX; int rank, nRanks;     // 8x8 tile grid + tile-interleaved partition
   int exitThreshold;                // leave the traversal loop below this many active lanes
+  int leafThreshold;                // run the leaf pass once this many lanes are parked at a leaf
   int* stackOverflow;               // per-thread spill area for trees deeper than the LDS stack (or null)
-  unsigned long long* counters;     // 11 x u64 (counting build only)
+  unsigned long long* counters;     // 16 x u64 (counting build only)
+  // variant 1 (poolkernel.hip)
+  void* poolCold;                   // per-wave slot records in HBM
+  int refillLanes;                  // refill from Q_TRAV once this many lanes are idle
+  int starveLanes;                  // shade a partial batch once this many lanes idle and Q_TRAV is empty
 };
 
+#if defined(__HIPCC__)
+// work item k -> (sample index, pixel).  Slot i = k % nItems is the (i & 63)-th pixel of this
+// rank's (i >> 6)-th 8x8 tile; tiles are dealt round-robin to the ranks in raster order
+// (tile-interleaved multi-GPU partition).  False for pixels outside the frame.
+__device__ __forceinline__ bool item_to_pixel(const LaunchArgs& a, int k, int& sample, int& pixel) {
+  sample = k / a.nItems;
+  const int i = k - sample * a.nItems;
+  const int lt = i >> 6, in = i & 63;
+  const int gt = lt * a.nRanks + a.rank;
+  const int tx = gt % a.tilesX, ty = gt / a.tilesX;
+  const int x = tx * 8 + (in & 7), y = ty * 8 + (in >> 3);
+  pixel = y * a.scene.width + x;
+  return (x < a.scene.width) & (y < a.scene.height);
+}
+// Camera.cu:39 result of one sample; Camera.cu:41 (the add) happens in k_reduce_samples
+__device__ __forceinline__ void store_sample(const LaunchArgs& a, int item, v3 value) {
+  float* sp = a.sampleBuf + 3 * (size_t)item;
+  sp[0] = value.x; sp[1] = value.y; sp[2] = value.z;
+}
+#endif
+
 int megakernel_lds_stack_entries();
+hipError_t launch_reduce_samples(hipStream_t stream, const LaunchArgs& a);
 hipError_t launch_megakernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted);
+int poolkernel_lds_stack_entries();
+size_t poolkernel_cold_bytes(int nBlocks, int poolSlots);
+hipError_t launch_poolkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, int poolSlots, bool counted);
 hipError_t launch_debug_trace(hipStream_t stream, const SceneView& sc, const float* dRays, int n, float* dT, int* dPrim, int* stackOverflow);
 hipError_t launch_resolve_rgb8(hipStream_t stream, float* accum, int width, int height, float nAccumulation, int clearBuffer, uint8_t* dOut);
 

@@ -57,16 +57,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
-// work item k -> pixel of this rank's k/64-th tile (tile-interleaved multi-GPU partition)
-__device__ __forceinline__ bool work_to_pixel(const LaunchArgs& a, int k, int& pixel) {
-  const int lt = k >> 6, in = k & 63;
-  const int gt = lt * a.nRanks + a.rank;
-  const int tx = gt % a.tilesX, ty = gt / a.tilesX;
-  const int x = tx * 8 + (in & 7), y = ty * 8 + (in >> 3);
-  pixel = y * a.scene.width + x;
-  return (x < a.scene.width) & (y < a.scene.height);
-}
-
 template <bool CNT, bool HAS_TRIS>
 __global__ void __launch_bounds__(kBlockThreads) pt_megakernel(const LaunchArgs a) {
   __shared__ int ldsStack[HAS_TRIS ? kWavesPerBlock * kLdsStack * 64 : 1];
@@ -83,7 +73,7 @@ __global__ void __launch_bounds__(kBlockThreads) pt_megakernel(const LaunchArgs 
   }
 
   PathState ps;
-  ps.mode = M_NEW_PIXEL; ps.pixel = 0; ps.sample = 0; ps.accum = mk3(0, 0, 0);
+  ps.mode = M_NEW_PIXEL; ps.pixel = 0; ps.item = 0; ps.accum = mk3(0, 0, 0);
   ps.thr = mk3(0, 0, 0); ps.rad = mk3(0, 0, 0); ps.depth = 0; ps.seed = 0;
   ps.o = mk3(0, 0, 0); ps.d = mk3(0, 0, 1); ps.tmin = 0; ps.tmax = 0; ps.kind = RK_RADIANCE;
   ps.N = mk3(0, 0, 1); ps.V = mk3(0, 0, 1); ps.mat = 0; ps.light = 0; ps.pendW = mk3(0, 0, 0); ps.pendInv = 0;
@@ -101,22 +91,13 @@ __global__ void __launch_bounds__(kBlockThreads) pt_megakernel(const LaunchArgs 
       } else if (ps.mode == M_LIGHTS) {
         on_lights<CNT>(sc, ps, ct);
       } else if (ps.mode == M_NEW_SAMPLE) {
-        if (ps.sample >= a.nSeeds) {
-          float* px = a.accum + 3 * (size_t)ps.pixel;
-          px[0] = ps.accum.x; px[1] = ps.accum.y; px[2] = ps.accum.z;
-          ps.mode = M_NEW_PIXEL;
-        } else {
-          begin_sample<CNT>(sc, ps, a.seeds[ps.sample], ct);
-        }
-      } else {  // M_NEW_PIXEL
+        store_sample(a, ps.item, ps.accum);                          // the finished sample -> per-sample buffer
+        ps.mode = M_NEW_PIXEL;
+      } else {  // M_NEW_PIXEL: next (pixel, sample) work item
         const int k = atomicAdd(a.workCounter, 1);     // hipcc aggregates this per wave
+        int s;
         if (k >= a.nWork) { ps.mode = M_DONE; }
-        else if (work_to_pixel(a, k, ps.pixel)) {
-          const float* px = a.accum + 3 * (size_t)ps.pixel;
-          ps.accum = mk3(px[0], px[1], px[2]);
-          ps.sample = 0;
-          ps.mode = M_NEW_SAMPLE;
-        }
+        else if (item_to_pixel(a, k, s, ps.pixel)) { ps.item = k; begin_sample<CNT>(sc, ps, a.seeds[s], ct); }
       }
     }
     if (__ballot(ps.mode != M_DONE) == 0ull) break;
@@ -134,8 +115,17 @@ __global__ void __launch_bounds__(kBlockThreads) pt_megakernel(const LaunchArgs 
           const unsigned long long wm = __ballot((ps.mode == M_TRACE) & (tv.node == kTravDone));
           if (wm != 0ull) break;
         }
-        if (CNT) { waveSteps++; activeLaneSteps += (uint32_t)nActive; }
-        if (active) trav_step<CNT>(sc, ps, tv, st, ct);
+        // while-while: node steps until enough lanes are parked at a leaf, then one leaf pass
+        const bool atNode = active & (tv.node >= 0);
+        const unsigned long long nm = __ballot(atNode);
+        const int nLeaf = nActive - popc64(nm);
+        if (nm != 0ull && nLeaf < a.leafThreshold) {
+          if (CNT) { waveSteps++; activeLaneSteps += (uint32_t)popc64(nm); }
+          if (atNode) trav_node_step<CNT>(sc, ps, tv, st, ct);
+        } else {
+          if (CNT) { waveSteps++; activeLaneSteps += (uint32_t)nLeaf; }
+          if (active & (tv.node < 0)) trav_leaf_step<CNT>(sc, ps, tv, st, ct);
+        }
       }
     } else {
       tv.node = kTravDone;
@@ -210,6 +200,27 @@ hipError_t launch_megakernel(hipStream_t stream, const LaunchArgs& a, int nBlock
 hipError_t launch_debug_trace(hipStream_t stream, const SceneView& sc, const float* dRays, int n, float* dT, int* dPrim, int* stackOverflow) {
   const int blocks = (n + kBlockThreads - 1) / kBlockThreads;
   k_debug_trace<<<blocks, kBlockThreads, 0, stream>>>(sc, dRays, n, dT, dPrim, stackOverflow);
+  return hipGetLastError();
+}
+
+// Camera.cu:41 for every launch of the batch: accu[pixel] += sample, strictly in launch order,
+// so the result is bit-identical to nSeeds separate one-sample launches.
+__global__ void k_reduce_samples(LaunchArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.nItems) return;
+  int s, pixel;
+  if (!item_to_pixel(a, i, s, pixel)) return;
+  float* px = a.accum + 3 * (size_t)pixel;
+  v3 acc = mk3(px[0], px[1], px[2]);
+  for (int k = 0; k < a.nSeeds; k++) {
+    const float* sp = a.sampleBuf + 3 * ((size_t)k * a.nItems + i);
+    acc = acc + mk3(sp[0], sp[1], sp[2]);
+  }
+  px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
+}
+
+hipError_t launch_reduce_samples(hipStream_t stream, const LaunchArgs& a) {
+  k_reduce_samples<<<(a.nItems + 255) / 256, 256, 0, stream>>>(a);
   return hipGetLastError();
 }
 

@@ -3,7 +3,9 @@
 // There is no CPU path: every entry point that computes needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -42,7 +44,7 @@ struct moptix_context_t {
   int device = 0;
   int numCUs = 256;
   hipStream_t stream = nullptr; bool ownStream = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   std::string err;
 
   moptix_params params{}; bool haveParams = false;
@@ -61,11 +63,14 @@ struct moptix_context_t {
   LbvhResult bvh;
   DevBuf<float> dAccum; float* accumBound = nullptr; size_t accumPixels = 0;
   DevBuf<int> dSeeds; DevBuf<int> dWork; DevBuf<unsigned long long> dCounters; DevBuf<int> dOverflow; DevBuf<uint8_t> dRgb8;
+  DevBuf<uint8_t> dPoolCold; DevBuf<float> dSampleBuf;
 
   int rank = 0, nRanks = 1;
-  int optExitThreshold = 40, optLeafSize = 4, optBlocksPerCU = 4, optVariant = 0;
+  int optExitThreshold = 16, optLeafSize = 4, optBlocksPerCU = 2, optVariant = 1;
+  int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 32, optSampleBufMB = 8192, optLeafThreshold = 16;
+  unsigned long long lastExtra[5] = { 0, 0, 0, 0, 0 };
 
-  double kernelMs = 0.0; uint64_t nLaunches = 0;
+  double kernelMs = 0.0, reduceMs = 0.0; uint64_t nLaunches = 0;
   bool asyncPending = false;
 };
 
@@ -117,55 +122,88 @@ int check_ready(moptix_context c) {
   return MOPTIX_OK;
 }
 
+int read_stats(moptix_context c, moptix_stats* stats) {
+  unsigned long long h[24];
+  HIPCHK(c, hipMemcpy(h, c->dCounters.p, sizeof(h), hipMemcpyDeviceToHost), "read counters");
+  stats->samples = h[0]; stats->primaryRays = h[1]; stats->bounceRays = h[2]; stats->shadowRays = h[3];
+  stats->nodeFetches = h[4]; stats->triTests = h[5]; stats->closestHits = h[6]; stats->lightLoads = h[7];
+  stats->analyticTests = h[8]; stats->traversalSteps = h[9]; stats->activeLaneSteps = h[10];
+  stats->shadeBatches = h[11]; stats->shadeBatchLanes = h[12];
+  if (getenv("MOPTIX_DEBUG")) {
+    fprintf(stderr, "[moptix] batches %llu lanes %llu full %llu allidle %llu waitingSum %llu\n", h[11], h[12], h[13], h[14], h[15]);
+    fprintf(stderr, "[moptix] per-step avg: qTrav %.2f qShade %.2f qGen %.2f done %.2f\n", (double)h[16] / h[9], (double)h[17] / h[9],
+            (double)h[18] / h[9], (double)h[19] / h[9]);
+  }
+  return MOPTIX_OK;
+}
+
+// One batch of launches = [trace kernel: every (pixel, sample) work item -> per-sample buffer]
+// + [ordered reduction: accuBuffer[pixel] += samples in launch order].  Batches larger than the
+// sample-buffer budget (or 2^31 work items) are cut into passes of whole launches.
 int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool counted, bool blocking, moptix_stats* stats) {
   int rc = check_ready(c);
   if (rc != MOPTIX_OK) return rc;
   if (nSeeds < 0 || (nSeeds > 0 && !seeds)) return fail(c, MOPTIX_ERR_INVALID, "bad seeds");
   HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  if ((rc = moptix_sync(c)) != MOPTIX_OK) return rc;     // one batch in flight at a time
   if ((rc = ensure_accum(c)) != MOPTIX_OK) return rc;
   if (nSeeds == 0) return MOPTIX_OK;
-
-  std::vector<int> hs(seeds, seeds + nSeeds);
-  HIPCHK(c, c->dSeeds.upload(hs, c->stream), "upload seeds");
-  HIPCHK(c, c->dWork.ensure(1), "alloc work counter");
-  HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, sizeof(int), c->stream), "zero work counter");
 
   LaunchArgs a;
   memset(&a, 0, sizeof(a));
   fill_view(c, a.scene);
-  a.seeds = c->dSeeds.p; a.nSeeds = nSeeds; a.accum = accum_ptr(c); a.workCounter = c->dWork.p;
+  a.accum = accum_ptr(c);
   const int tilesX = ((int)c->params.width + 7) / 8, tilesY = ((int)c->params.height + 7) / 8;
   const long long nTiles = (long long)tilesX * tilesY;
   const long long localTiles = (nTiles - c->rank + c->nRanks - 1) / c->nRanks;
-  if (localTiles * 64 > 0x7fffffffLL) return fail(c, MOPTIX_ERR_LIMIT, "frame too large for 32-bit work counter");
-  a.nWork = (int)(localTiles * 64); a.tilesX = tilesX; a.rank = c->rank; a.nRanks = c->nRanks;
-  a.exitThreshold = c->optExitThreshold;
+  if (localTiles * 64 > 0x7fffffffLL) return fail(c, MOPTIX_ERR_LIMIT, "frame too large");
+  a.nItems = (int)(localTiles * 64); a.tilesX = tilesX; a.rank = c->rank; a.nRanks = c->nRanks;
+  a.exitThreshold = c->optExitThreshold; a.leafThreshold = c->optLeafThreshold;
+  if (a.nItems == 0) return MOPTIX_OK;
+  const long long budget = (long long)c->optSampleBufMB << 20;
+  long long perPass = budget / ((long long)a.nItems * 12);
+  perPass = std::min(perPass, 0x7fffffffLL / a.nItems);
+  perPass = std::max(1LL, std::min(perPass, (long long)nSeeds));
+
   const int nBlocks = c->numCUs * c->optBlocksPerCU;
-  a.stackOverflow = nullptr;
-  if (c->bvh.depth > megakernel_lds_stack_entries()) {
-    const size_t need = (size_t)(c->bvh.depth - megakernel_lds_stack_entries() + 1) * nBlocks * 256;
+  const bool usePool = c->optVariant == 1 && a.scene.rootRef != kEmptyRef;
+  const int ldsStack = usePool ? poolkernel_lds_stack_entries() : megakernel_lds_stack_entries();
+  if (c->bvh.depth > ldsStack) {
+    const size_t need = (size_t)(c->bvh.depth - ldsStack + 1) * nBlocks * 256;
     HIPCHK(c, c->dOverflow.ensure(need), "alloc stack overflow area");
     a.stackOverflow = c->dOverflow.p;
   }
+  if (usePool) {
+    HIPCHK(c, c->dPoolCold.ensure(poolkernel_cold_bytes(nBlocks, c->optPoolSlots)), "alloc path pool");
+    a.poolCold = c->dPoolCold.p; a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes;
+  }
+  HIPCHK(c, c->dSampleBuf.ensure((size_t)perPass * a.nItems * 3), "alloc per-sample buffer");
+  a.sampleBuf = c->dSampleBuf.p;
+  HIPCHK(c, c->dWork.ensure(1), "alloc work counter");
+  a.workCounter = c->dWork.p;
   if (counted) {
-    HIPCHK(c, c->dCounters.ensure(16), "alloc counters");
-    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * 16, c->stream), "zero counters");
+    HIPCHK(c, c->dCounters.ensure(24), "alloc counters");
+    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * 24, c->stream), "zero counters");
     a.counters = c->dCounters.p;
   }
-  HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
-  HIPCHK(c, launch_megakernel(c->stream, a, nBlocks, counted), "launch megakernel");
-  HIPCHK(c, hipEventRecord(c->ev1, c->stream), "event");
-  c->asyncPending = true;
-  if (!blocking) return MOPTIX_OK;
-  rc = moptix_sync(c);
-  if (rc != MOPTIX_OK) return rc;
-  if (counted && stats) {
-    unsigned long long h[16];
-    HIPCHK(c, hipMemcpy(h, c->dCounters.p, sizeof(h), hipMemcpyDeviceToHost), "read counters");
-    stats->samples = h[0]; stats->primaryRays = h[1]; stats->bounceRays = h[2]; stats->shadowRays = h[3];
-    stats->nodeFetches = h[4]; stats->triTests = h[5]; stats->closestHits = h[6]; stats->lightLoads = h[7];
-    stats->analyticTests = h[8]; stats->traversalSteps = h[9]; stats->activeLaneSteps = h[10];
+  std::vector<int> hs(seeds, seeds + nSeeds);
+  HIPCHK(c, c->dSeeds.upload(hs, c->stream), "upload seeds");
+
+  for (long long first = 0; first < nSeeds; first += perPass) {
+    const int n = (int)std::min(perPass, (long long)nSeeds - first);
+    a.seeds = c->dSeeds.p + first; a.nSeeds = n; a.nWork = n * a.nItems;
+    HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, sizeof(int), c->stream), "zero work counter");
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
+    if (usePool) HIPCHK(c, launch_poolkernel(c->stream, a, nBlocks, c->optPoolSlots, counted), "launch pool megakernel");
+    else HIPCHK(c, launch_megakernel(c->stream, a, nBlocks, counted), "launch megakernel");
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream), "event");
+    HIPCHK(c, launch_reduce_samples(c->stream, a), "launch sample reduction");
+    HIPCHK(c, hipEventRecord(c->ev2, c->stream), "event");
+    c->asyncPending = true;
+    const bool last = first + perPass >= nSeeds;
+    if (!last || blocking) { if ((rc = moptix_sync(c)) != MOPTIX_OK) return rc; }
   }
+  if (blocking && counted && stats) return read_stats(c, stats);
   return MOPTIX_OK;
 }
 
@@ -196,7 +234,7 @@ int moptix_create(moptix_context* out, int device) {
   c->device = device; c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipFail(nullptr, e, "hipStreamCreate"); }
   c->ownStream = true;
-  if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) { delete c; return hipFail(nullptr, e, "hipEventCreate"); }
+  if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess || (e = hipEventCreate(&c->ev2)) != hipSuccess) { delete c; return hipFail(nullptr, e, "hipEventCreate"); }
   *out = c;
   return MOPTIX_OK;
 }
@@ -208,9 +246,11 @@ int moptix_destroy(moptix_context c) {
   c->dMats.release(); c->dSpheres.release(); c->dSphereMat.release(); c->dQuads.release(); c->dLights.release();
   c->dFacePos.release(); c->dFaceNrm.release(); c->dFaceHasNrm.release(); c->dFaceMat.release();
   lbvh_free(&c->bvh);
+  c->dPoolCold.release(); c->dSampleBuf.release();
   c->dAccum.release(); c->dSeeds.release(); c->dWork.release(); c->dCounters.release(); c->dOverflow.release(); c->dRgb8.release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev2) (void)hipEventDestroy(c->ev2);
   if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return MOPTIX_OK;
@@ -381,8 +421,9 @@ int moptix_sync(moptix_context c) {
   if (!c) return MOPTIX_ERR_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream), "stream synchronize");
   if (c->asyncPending) {
-    float ms = 0.f;
+    float ms = 0.f, ms2 = 0.f;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) { c->kernelMs += ms; c->nLaunches++; }
+    if (hipEventElapsedTime(&ms2, c->ev1, c->ev2) == hipSuccess) c->reduceMs += ms2;
     c->asyncPending = false;
   }
   return MOPTIX_OK;
@@ -399,7 +440,12 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   if (!strcmp(name, "exit_threshold")) { if (value < 0 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "exit_threshold in [0,64]"); c->optExitThreshold = value; }
   else if (!strcmp(name, "leaf_size")) { if (value < 1 || value > kMaxLeaf) return fail(c, MOPTIX_ERR_INVALID, "leaf_size in [1,8]"); if (value != c->optLeafSize) c->accelBuilt = false; c->optLeafSize = value; }
   else if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) return fail(c, MOPTIX_ERR_INVALID, "blocks_per_cu in [1,8]"); c->optBlocksPerCU = value; }
-  else if (!strcmp(name, "kernel_variant")) { c->optVariant = value; }
+  else if (!strcmp(name, "kernel_variant")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {0,1}"); c->optVariant = value; }
+  else if (!strcmp(name, "pool_slots")) { if (value != 128 && value != 192 && value != 256) return fail(c, MOPTIX_ERR_INVALID, "pool_slots in {128,192,256}"); c->optPoolSlots = value; }
+  else if (!strcmp(name, "sample_buffer_mb")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "sample_buffer_mb >= 1"); c->optSampleBufMB = value; }
+  else if (!strcmp(name, "leaf_threshold")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "leaf_threshold in [1,64]"); c->optLeafThreshold = value; }
+  else if (!strcmp(name, "refill_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "refill_lanes in [1,64]"); c->optRefillLanes = value; }
+  else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
 }
@@ -410,6 +456,11 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "leaf_size")) *value = c->optLeafSize;
   else if (!strcmp(name, "blocks_per_cu")) *value = c->optBlocksPerCU;
   else if (!strcmp(name, "kernel_variant")) *value = c->optVariant;
+  else if (!strcmp(name, "pool_slots")) *value = c->optPoolSlots;
+  else if (!strcmp(name, "sample_buffer_mb")) *value = c->optSampleBufMB;
+  else if (!strcmp(name, "leaf_threshold")) *value = c->optLeafThreshold;
+  else if (!strcmp(name, "refill_lanes")) *value = c->optRefillLanes;
+  else if (!strcmp(name, "starve_lanes")) *value = c->optStarveLanes;
   else if (!strcmp(name, "num_cus")) *value = c->numCUs;
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
@@ -473,7 +524,13 @@ int moptix_kernel_time(moptix_context c, double* totalMs, uint64_t* nLaunches, i
   if (!c) return MOPTIX_ERR_INVALID;
   if (totalMs) *totalMs = c->kernelMs;
   if (nLaunches) *nLaunches = c->nLaunches;
-  if (reset) { c->kernelMs = 0.0; c->nLaunches = 0; }
+  if (reset) { c->kernelMs = 0.0; c->reduceMs = 0.0; c->nLaunches = 0; }
+  return MOPTIX_OK;
+}
+
+int moptix_reduce_time(moptix_context c, double* totalMs) {
+  if (!c || !totalMs) return MOPTIX_ERR_INVALID;
+  *totalMs = c->reduceMs;
   return MOPTIX_OK;
 }
 

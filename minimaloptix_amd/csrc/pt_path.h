@@ -4,7 +4,8 @@
 // is flattened into   L = sum_k (prod_{j<k} w_j) * e_k   with the RNG draw order and the
 // seed forks of SURVEY A2 preserved, so a lane always owns exactly one ray in flight:
 //
-//   M_NEW_PIXEL -> M_NEW_SAMPLE -> [M_TRACE -> M_RESULT (-> M_LIGHTS -> M_TRACE ...)]* -> M_NEW_SAMPLE
+//   M_NEW_PIXEL (fetch a (pixel,sample) work item) -> [M_TRACE -> M_RESULT (-> M_LIGHTS -> M_TRACE ...)]*
+//       -> M_NEW_SAMPLE (sample finished, its clamped value is in ps.accum) -> M_NEW_PIXEL
 //
 // Traversal state (Trav) lives in registers + an LDS stack and is resumable at any step,
 // which is what lets the kernel leave the traversal loop when too few lanes of the wave
@@ -41,8 +42,8 @@ struct Trav {
 struct PathState {
   int mode;
   int pixel;           // y*W + x
-  int sample;          // index of the next launch seed
-  v3 accum;            // accuBuffer[pixel] carried in registers across the samples
+  int item;            // work-item index = slot of this sample in the per-sample buffer
+  v3 accum;            // the finished sample's clamped colour (valid in M_NEW_SAMPLE)
   v3 thr, rad;         // path throughput and accumulated radiance of the current sample
   int depth; uint32_t seed;
   v3 o, d; float tmin, tmax; int kind;    // the ray in flight
@@ -127,11 +128,10 @@ PT_HD void trav_pop(Trav& tv, Stack& st) {
   else { tv.sp--; tv.node = st.load(tv.sp); }
 }
 
-// One traversal step for a lane with tv.node != kTravDone: either one two-child node
-// (one 64-byte fetch) or one leaf (count x 48-byte triangle records).
+// One two-child node (one 64-byte fetch) for a lane with tv.node >= 0.
 template <bool CNT, class Stack>
-PT_HD void trav_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
-  if (tv.node >= 0) {
+PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
+  {
     const Node64* np = sc.nodes + tv.node;
     const v4 a = np->a, b = np->b, c = np->c;
     const int c0 = np->c0, c1 = np->c1;
@@ -146,7 +146,13 @@ PT_HD void trav_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& 
     } else if (h0) tv.node = c0;
     else if (h1) tv.node = c1;
     else trav_pop(tv, st);
-  } else {
+  }
+}
+
+// One leaf (count x 48-byte triangle records) for a lane with tv.node < 0.
+template <bool CNT, class Stack>
+PT_HD void trav_leaf_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
+  {
     const int first = leaf_first(tv.node), count = leaf_count(tv.node);
     const int triBase = sc.nSpheres + sc.nQuads;
     bool terminated = false;
@@ -167,6 +173,14 @@ PT_HD void trav_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& 
     if (terminated) tv.node = kTravDone;
     else trav_pop(tv, st);
   }
+}
+
+// One traversal step for a lane with tv.node != kTravDone (if-if form; the kernels use the
+// two halves separately as a while-while loop).
+template <bool CNT, class Stack>
+PT_HD void trav_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
+  if (tv.node >= 0) trav_node_step<CNT>(sc, ps, tv, st, ct);
+  else trav_leaf_step<CNT>(sc, ps, tv, st, ct);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -192,10 +206,10 @@ PT_HD void begin_sample(const SceneView& sc, PathState& ps, int launchSeed, Coun
   cnt<CNT>(ct.samples); cnt<CNT>(ct.primaryRays);
 }
 
-// Camera.cu:39-41: clamp the sample and add it to the accumulator
+// Camera.cu:39: clamp the sample.  The add into accuBuffer (Camera.cu:41) is done by the
+// caller, in launch order per pixel (ordered reduction over the per-sample buffer).
 PT_HD void end_sample(PathState& ps) {
-  ps.accum = ps.accum + mk3(clampf(ps.rad.x, 0.f, 1.f), clampf(ps.rad.y, 0.f, 1.f), clampf(ps.rad.z, 0.f, 1.f));
-  ps.sample++;
+  ps.accum = mk3(clampf(ps.rad.x, 0.f, 1.f), clampf(ps.rad.y, 0.f, 1.f), clampf(ps.rad.z, 0.f, 1.f));
   ps.mode = M_NEW_SAMPLE;
 }
 

@@ -204,13 +204,15 @@ int hostsim_render(const hostsim_scene* s, int leafSize, const int32_t* seeds, i
       Trav tv; memset(&tv, 0, sizeof(tv));
       Counters ct; memset(&ct, 0, sizeof(ct));
       LocalStack st;
-      ps.pixel = pix; ps.sample = 0;
-      ps.accum = mk3(accum[3 * pix], accum[3 * pix + 1], accum[3 * pix + 2]);
-      ps.mode = M_NEW_SAMPLE;
-      for (;;) {
-        if (ps.mode == M_NEW_SAMPLE) {
-          if (ps.sample >= nSeeds) break;
-          begin_sample<true>(sc, ps, seeds[ps.sample], ct);
+      ps.pixel = pix; ps.item = 0;
+      v3 acc = mk3(accum[3 * pix], accum[3 * pix + 1], accum[3 * pix + 2]);
+      int sIdx = 0;
+      if (nSeeds > 0) begin_sample<true>(sc, ps, seeds[0], ct); else ps.mode = M_DONE;
+      while (ps.mode != M_DONE) {
+        if (ps.mode == M_NEW_SAMPLE) {            // Camera.cu:41, one launch after the other
+          acc = acc + ps.accum;
+          if (++sIdx >= nSeeds) break;
+          begin_sample<true>(sc, ps, seeds[sIdx], ct);
         } else if (ps.mode == M_TRACE) {
           trav_begin<true>(sc, ps, tv, ct);
           while (tv.node != kTravDone) trav_step<true>(sc, ps, tv, st, ct);
@@ -221,6 +223,7 @@ int hostsim_render(const hostsim_scene* s, int leafSize, const int32_t* seeds, i
           on_lights<true>(sc, ps, ct);
         }
       }
+      ps.accum = acc;
       accum[3 * pix] = ps.accum.x; accum[3 * pix + 1] = ps.accum.y; accum[3 * pix + 2] = ps.accum.z;
       loc[0] += ct.samples; loc[1] += ct.primaryRays; loc[2] += ct.bounceRays; loc[3] += ct.shadowRays;
       loc[4] += ct.nodeFetches; loc[5] += ct.triTests; loc[6] += ct.closestHits; loc[7] += ct.lightLoads; loc[8] += ct.analyticTests;
