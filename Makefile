@@ -12,11 +12,14 @@ CSRC     := minimaloptix_amd/csrc
 HOST     := minimaloptix_amd/host
 
 # -ffp-contract=off: arithmetic contract AC4; explicit fmaf() where a fused op is specified
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -include cstring
+EXTRA    ?=
+LIBNAME  ?= libmoptix.so
+BUILD    ?= build
+HIPFLAGS := $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -include cstring
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -mavx2 -mfma -Wall -Wno-unused-function -Wno-unknown-pragmas
 
-DEV_SRCS := $(CSRC)/moptix_api.hip $(CSRC)/megakernel.hip $(CSRC)/poolkernel.hip $(CSRC)/lbvh.hip
-DEV_OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(DEV_SRCS))
+DEV_SRCS := $(CSRC)/moptix_api.hip $(CSRC)/megakernel.hip $(CSRC)/poolkernel.hip $(CSRC)/queuekernel.hip $(CSRC)/lbvh.hip
+DEV_OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(DEV_SRCS))
 DEV_HDRS := $(wildcard $(CSRC)/*.h) include/moptix.h
 HOST_SRCS := $(HOST)/obj_loader.cpp $(HOST)/scene_file.cpp $(HOST)/scenes.cpp $(HOST)/standin_scenes.cpp \
              $(HOST)/image_io.cpp $(HOST)/minimal_optix.cpp $(HOST)/host_capi.cpp
@@ -25,18 +28,18 @@ HOST_HDRS := $(wildcard $(HOST)/*.h) $(wildcard $(CSRC)/pt_*.h) include/moptix.h
 
 all: device host oracle hostsim
 
-device: $(LIBDIR)/libmoptix.so
+device: $(LIBDIR)/$(LIBNAME)
 host: $(LIBDIR)/libmoptix_host.so $(LIBDIR)/moptix_render
 oracle:
 	$(MAKE) -C oracle -s
 hostsim:
 	$(MAKE) -C tests/hostsim -s
 
-build/%.o: $(CSRC)/%.hip $(DEV_HDRS)
-	@mkdir -p build
+$(BUILD)/%.o: $(CSRC)/%.hip $(DEV_HDRS)
+	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/libmoptix.so: $(DEV_OBJS)
+$(LIBDIR)/$(LIBNAME): $(DEV_OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(DEV_OBJS)
 

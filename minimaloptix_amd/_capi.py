@@ -130,7 +130,7 @@ def _load(name):
 def device_lib():
     global _dev
     if _dev is None:
-        L = _load("libmoptix.so")
+        L = _load(os.environ.get("MOPTIX_DEVICE_LIB", "libmoptix.so"))   # alternate builds for A/B experiments
         vp, i32, f32p, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)
         L.moptix_create.argtypes = [C.POINTER(vp), C.c_int]
         L.moptix_destroy.argtypes = [vp]

@@ -22,6 +22,9 @@ struct LaunchArgs {
   void* poolCold;                   // per-wave slot records in HBM
   int refillLanes;                  // refill from Q_TRAV once this many lanes are idle
   int starveLanes;                  // shade a partial batch once this many lanes idle and Q_TRAV is empty
+  // variant 2 (queuekernel.hip)
+  int swapLanes;                    // leave the node loop once this many lanes stand at a leaf / have finished
+  int ovfDepth;                     // ints of stack overflow per slot
 };
 
 #if defined(__HIPCC__)
@@ -51,6 +54,11 @@ hipError_t launch_megakernel(hipStream_t stream, const LaunchArgs& a, int nBlock
 int poolkernel_lds_stack_entries();
 size_t poolkernel_cold_bytes(int nBlocks, int poolSlots);
 hipError_t launch_poolkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, int poolSlots, bool counted);
+int queuekernel_lds_stack_entries();
+int queuekernel_slots();
+size_t queuekernel_cold_bytes(int nBlocks);
+size_t queuekernel_overflow_ints(int nBlocks, int ovfDepth);
+hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool shared, bool counted);
 hipError_t launch_debug_trace(hipStream_t stream, const SceneView& sc, const float* dRays, int n, float* dT, int* dPrim, int* stackOverflow);
 hipError_t launch_resolve_rgb8(hipStream_t stream, float* accum, int width, int height, float nAccumulation, int clearBuffer, uint8_t* dOut);
 

@@ -66,8 +66,8 @@ struct moptix_context_t {
   DevBuf<uint8_t> dPoolCold; DevBuf<float> dSampleBuf;
 
   int rank = 0, nRanks = 1;
-  int optExitThreshold = 16, optLeafSize = 4, optBlocksPerCU = 2, optVariant = 1;
-  int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 32, optSampleBufMB = 8192, optLeafThreshold = 16;
+  int optExitThreshold = 16, optLeafSize = 4, optBlocksPerCU = 2, optVariant = 3;
+  int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 8192, optLeafThreshold = 16, optSwapLanes = 24;
   unsigned long long lastExtra[5] = { 0, 0, 0, 0, 0 };
 
   double kernelMs = 0.0, reduceMs = 0.0; uint64_t nLaunches = 0;
@@ -131,8 +131,12 @@ int read_stats(moptix_context c, moptix_stats* stats) {
   stats->shadeBatches = h[11]; stats->shadeBatchLanes = h[12];
   if (getenv("MOPTIX_DEBUG")) {
     fprintf(stderr, "[moptix] batches %llu lanes %llu full %llu allidle %llu waitingSum %llu\n", h[11], h[12], h[13], h[14], h[15]);
-    fprintf(stderr, "[moptix] per-step avg: qTrav %.2f qShade %.2f qGen %.2f done %.2f\n", (double)h[16] / h[9], (double)h[17] / h[9],
-            (double)h[18] / h[9], (double)h[19] / h[9]);
+    const double tt = (double)h[21];
+    fprintf(stderr, "[moptix] wave time: batch %.1f%% refill %.1f%% node %.1f%% leaf %.1f%% finish %.1f%% (steps %llu, cycles/wave %.3g)\n",
+            100 * h[16] / tt, 100 * h[17] / tt, 100 * h[18] / tt, 100 * h[19] / tt, 100 * h[20] / tt, h[9], tt);
+    fprintf(stderr, "[moptix] idle spins %llu\n", h[14]);
+    if (h[22]) fprintf(stderr, "[moptix] node steps %llu (%.1f lanes avg), leaf passes %llu (%.1f lanes avg)\n", h[9] - h[22],
+            (double)(h[10] - h[23]) / (double)(h[9] - h[22]), h[22], (double)h[23] / (double)h[22]);
   }
   return MOPTIX_OK;
 }
@@ -166,20 +170,33 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   perPass = std::max(1LL, std::min(perPass, (long long)nSeeds));
 
   const int nBlocks = c->numCUs * c->optBlocksPerCU;
-  const bool usePool = c->optVariant == 1 && a.scene.rootRef != kEmptyRef;
-  const int ldsStack = usePool ? poolkernel_lds_stack_entries() : megakernel_lds_stack_entries();
-  if (c->bvh.depth > ldsStack) {
-    const size_t need = (size_t)(c->bvh.depth - ldsStack + 1) * nBlocks * 256;
-    HIPCHK(c, c->dOverflow.ensure(need), "alloc stack overflow area");
-    a.stackOverflow = c->dOverflow.p;
-  }
-  if (usePool) {
-    HIPCHK(c, c->dPoolCold.ensure(poolkernel_cold_bytes(nBlocks, c->optPoolSlots)), "alloc path pool");
-    a.poolCold = c->dPoolCold.p; a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes;
+  const bool hasTris = a.scene.rootRef != kEmptyRef;
+  const bool usePool = c->optVariant == 1 && hasTris;
+  const bool useQueue = (c->optVariant == 2 || c->optVariant == 3) && hasTris;
+  a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;
+  if (useQueue) {
+    a.ovfDepth = std::max(0, c->bvh.depth - queuekernel_lds_stack_entries() + 1);
+    if (a.ovfDepth > 0) {
+      HIPCHK(c, c->dOverflow.ensure(queuekernel_overflow_ints(nBlocks, a.ovfDepth)), "alloc stack overflow area");
+      a.stackOverflow = c->dOverflow.p;
+    }
+    HIPCHK(c, c->dPoolCold.ensure(queuekernel_cold_bytes(nBlocks)), "alloc path pool");
+    a.poolCold = c->dPoolCold.p;
+  } else {
+    const int ldsStack = usePool ? poolkernel_lds_stack_entries() : megakernel_lds_stack_entries();
+    if (c->bvh.depth > ldsStack) {
+      const size_t need = (size_t)(c->bvh.depth - ldsStack + 1) * nBlocks * 256;
+      HIPCHK(c, c->dOverflow.ensure(need), "alloc stack overflow area");
+      a.stackOverflow = c->dOverflow.p;
+    }
+    if (usePool) {
+      HIPCHK(c, c->dPoolCold.ensure(poolkernel_cold_bytes(nBlocks, c->optPoolSlots)), "alloc path pool");
+      a.poolCold = c->dPoolCold.p;
+    }
   }
   HIPCHK(c, c->dSampleBuf.ensure((size_t)perPass * a.nItems * 3), "alloc per-sample buffer");
   a.sampleBuf = c->dSampleBuf.p;
-  HIPCHK(c, c->dWork.ensure(1), "alloc work counter");
+  HIPCHK(c, c->dWork.ensure(2), "alloc work counter");   // [0] work counter, [1] watchdog flag
   a.workCounter = c->dWork.p;
   if (counted) {
     HIPCHK(c, c->dCounters.ensure(24), "alloc counters");
@@ -192,9 +209,10 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   for (long long first = 0; first < nSeeds; first += perPass) {
     const int n = (int)std::min(perPass, (long long)nSeeds - first);
     a.seeds = c->dSeeds.p + first; a.nSeeds = n; a.nWork = n * a.nItems;
-    HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, sizeof(int), c->stream), "zero work counter");
+    HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, 2 * sizeof(int), c->stream), "zero work counter");
     HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
-    if (usePool) HIPCHK(c, launch_poolkernel(c->stream, a, nBlocks, c->optPoolSlots, counted), "launch pool megakernel");
+    if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, c->optVariant == 3, counted), "launch queue megakernel");
+    else if (usePool) HIPCHK(c, launch_poolkernel(c->stream, a, nBlocks, c->optPoolSlots, counted), "launch pool megakernel");
     else HIPCHK(c, launch_megakernel(c->stream, a, nBlocks, counted), "launch megakernel");
     HIPCHK(c, hipEventRecord(c->ev1, c->stream), "event");
     HIPCHK(c, launch_reduce_samples(c->stream, a), "launch sample reduction");
@@ -425,6 +443,9 @@ int moptix_sync(moptix_context c) {
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) { c->kernelMs += ms; c->nLaunches++; }
     if (hipEventElapsedTime(&ms2, c->ev1, c->ev2) == hipSuccess) c->reduceMs += ms2;
     c->asyncPending = false;
+    int flags[2] = { 0, 0 };
+    if (c->dWork.p) HIPCHK(c, hipMemcpy(flags, c->dWork.p, sizeof(flags), hipMemcpyDeviceToHost), "read watchdog flag");
+    if (flags[1] != 0) return fail(c, MOPTIX_ERR_HIP, "render kernel hit its iteration watchdog (scheduler made no progress)");
   }
   return MOPTIX_OK;
 }
@@ -440,10 +461,11 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   if (!strcmp(name, "exit_threshold")) { if (value < 0 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "exit_threshold in [0,64]"); c->optExitThreshold = value; }
   else if (!strcmp(name, "leaf_size")) { if (value < 1 || value > kMaxLeaf) return fail(c, MOPTIX_ERR_INVALID, "leaf_size in [1,8]"); if (value != c->optLeafSize) c->accelBuilt = false; c->optLeafSize = value; }
   else if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) return fail(c, MOPTIX_ERR_INVALID, "blocks_per_cu in [1,8]"); c->optBlocksPerCU = value; }
-  else if (!strcmp(name, "kernel_variant")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {0,1}"); c->optVariant = value; }
+  else if (!strcmp(name, "kernel_variant")) { if (value < 0 || value > 3) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {0,1,2,3}"); c->optVariant = value; }
   else if (!strcmp(name, "pool_slots")) { if (value != 128 && value != 192 && value != 256) return fail(c, MOPTIX_ERR_INVALID, "pool_slots in {128,192,256}"); c->optPoolSlots = value; }
   else if (!strcmp(name, "sample_buffer_mb")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "sample_buffer_mb >= 1"); c->optSampleBufMB = value; }
   else if (!strcmp(name, "leaf_threshold")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "leaf_threshold in [1,64]"); c->optLeafThreshold = value; }
+  else if (!strcmp(name, "swap_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "swap_lanes in [1,64]"); c->optSwapLanes = value; }
   else if (!strcmp(name, "refill_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "refill_lanes in [1,64]"); c->optRefillLanes = value; }
   else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
@@ -459,6 +481,7 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "pool_slots")) *value = c->optPoolSlots;
   else if (!strcmp(name, "sample_buffer_mb")) *value = c->optSampleBufMB;
   else if (!strcmp(name, "leaf_threshold")) *value = c->optLeafThreshold;
+  else if (!strcmp(name, "swap_lanes")) *value = c->optSwapLanes;
   else if (!strcmp(name, "refill_lanes")) *value = c->optRefillLanes;
   else if (!strcmp(name, "starve_lanes")) *value = c->optStarveLanes;
   else if (!strcmp(name, "num_cus")) *value = c->numCUs;

@@ -70,8 +70,11 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // hit record kept in the slot: >= 0 triangle record index, < 0 (and != kMiss) ~analytic prim id
 constexpr int kMiss = (int)0x80000000;
 
+#ifndef PT_POOL_WAVES_PER_SIMD
+#define PT_POOL_WAVES_PER_SIMD 1
+#endif
 template <bool CNT, int P>
-__global__ void __launch_bounds__(kBlockThreads) pt_poolkernel(const LaunchArgs a) {
+__global__ void __launch_bounds__(kBlockThreads, PT_POOL_WAVES_PER_SIMD) pt_poolkernel(const LaunchArgs a) {
   static_assert(P <= kRing && (P % 64) == 0, "pool size");
   __shared__ v4 sHot[kWaves][3][P];
   __shared__ int sStack[kWaves][kStackN * 64];
@@ -128,7 +131,9 @@ __global__ void __launch_bounds__(kBlockThreads) pt_poolkernel(const LaunchArgs 
   Trav tv; tv.node = kTravDone; tv.sp = 0; tv.started = 0; tv.tbest = 0; tv.bestPrim = -1; tv.bestTri = -1;
   tv.beta = 0; tv.gamma = 0; tv.att = mk3(1, 1, 1); tv.inv = mk3(0, 0, 0);
   Counters ct = {};
-  uint32_t waveSteps = 0, activeLaneSteps = 0, batchLanes = 0, batches = 0, dbgFull = 0, dbgIdle = 0, dbgWaiting = 0; unsigned long long dbgQT = 0, dbgQS = 0, dbgQG = 0, dbgDone = 0;
+  uint32_t leafPasses = 0, leafLanes = 0, waveSteps = 0, activeLaneSteps = 0, batchLanes = 0, batches = 0, dbgFull = 0, dbgIdle = 0, dbgWaiting = 0; unsigned long long tBatch = 0, tRefill = 0, tNode = 0, tLeaf = 0, tFin = 0, tStamp = 0; const unsigned long long tStart = CNT ? __builtin_amdgcn_s_memtime() : 0ull;
+#define PT_STAMP(acc) do { if (CNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tStamp; tStamp = now_; } } while (0)
+  tStamp = tStart;
 
   // Run the path state machine for up to 64 slots popped from queue q.
   auto run_batch = [&](int q) {
@@ -221,7 +226,8 @@ __global__ void __launch_bounds__(kBlockThreads) pt_poolkernel(const LaunchArgs 
         if (CNT) dbgWaiting += (uint32_t)waiting;
       }
     }
-    if (bq >= 0) { run_batch(bq); continue; }
+    PT_STAMP(tRefill);
+    if (bq >= 0) { run_batch(bq); PT_STAMP(tBatch); continue; }
 
     // ---- traversal steps ----
     for (;;) {
@@ -233,18 +239,20 @@ __global__ void __launch_bounds__(kBlockThreads) pt_poolkernel(const LaunchArgs 
         const int nLeaf = __popcll(__ballot((job >= 0) & (tv.node < 0)));
         const int nFin = __popcll(__ballot((job >= 0) & (tv.node == kTravDone)));
         if (nLeaf >= a.leafThreshold || nFin >= a.refillLanes) break;
-        if (CNT) { waveSteps++; activeLaneSteps += (uint32_t)__popcll(nm); dbgQT += qCount[Q_TRAV]; dbgQS += qCount[Q_SHADE]; dbgQG += qCount[Q_GEN]; dbgDone += nDone; }
+        if (CNT) { waveSteps++; activeLaneSteps += (uint32_t)__popcll(nm); }
         if (atNode) trav_node_step<CNT>(sc, ray, tv, st, ct);
       }
+      PT_STAMP(tNode);
       // ... then one leaf pass for the parked lanes
       {
         const bool atLeaf = (job >= 0) & (tv.node < 0);
         const unsigned long long lm = __ballot(atLeaf);
         if (lm != 0ull) {
-          if (CNT) { waveSteps++; activeLaneSteps += (uint32_t)__popcll(lm); }
+          if (CNT) { waveSteps++; activeLaneSteps += (uint32_t)__popcll(lm); leafPasses++; leafLanes += (uint32_t)__popcll(lm); }
           if (atLeaf) trav_leaf_step<CNT>(sc, ray, tv, st, ct);
         }
       }
+      PT_STAMP(tLeaf);
       const bool active = job >= 0;
       const bool fin = active && tv.node == kTravDone;
       const unsigned long long finMask = __ballot(fin);
@@ -265,6 +273,7 @@ __global__ void __launch_bounds__(kBlockThreads) pt_poolkernel(const LaunchArgs 
         if (fin) { job = -1; tv.started = 0; }
       }
       const int idle = 64 - __popcll(__ballot(job >= 0));
+      PT_STAMP(tFin);
       if (qCount[Q_SHADE] >= 64 || qCount[Q_GEN] >= 64) break;
       if (idle >= a.refillLanes && qCount[Q_TRAV] > 0) break;
       if (idle >= a.starveLanes && qCount[Q_TRAV] == 0 && (qCount[Q_SHADE] + qCount[Q_GEN]) > 0) break;
@@ -287,7 +296,9 @@ __global__ void __launch_bounds__(kBlockThreads) pt_poolkernel(const LaunchArgs 
       atomicAdd(&c[14], (unsigned long long)dbgIdle);
       atomicAdd(&c[15], (unsigned long long)dbgWaiting);
       if (nDone != P) atomicAdd(&c[9], 1ull << 60);
-      atomicAdd(&c[16], dbgQT); atomicAdd(&c[17], dbgQS); atomicAdd(&c[18], dbgQG); atomicAdd(&c[19], dbgDone);
+      atomicAdd(&c[16], tBatch); atomicAdd(&c[17], tRefill); atomicAdd(&c[18], tNode); atomicAdd(&c[19], tLeaf); atomicAdd(&c[20], tFin);
+      atomicAdd(&c[21], __builtin_amdgcn_s_memtime() - tStart);
+      atomicAdd(&c[22], (unsigned long long)leafPasses); atomicAdd(&c[23], (unsigned long long)leafLanes);
     }
   }
   (void)nDone;

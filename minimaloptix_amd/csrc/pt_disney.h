@@ -59,7 +59,7 @@ PT_HD v3 cosine_sample_hemisphere(float u1, float u2) {
 }
 
 // disney.h:9-30
-PT_HD void disney_sample(uint32_t& seed, const DevMaterial& m, v3 N, v3 V, v3& L, v3& H) {
+PT_HD_BRDF void disney_sample(uint32_t& seed, const DevMaterial& m, v3 N, v3 V, v3& L, v3& H) {
   Onb onb = make_onb(N);
   if (rnd(seed) < m.diffuseRatio) {
     float u1 = rnd(seed); float u2 = rnd(seed);
@@ -83,7 +83,7 @@ PT_HD void disney_sample(uint32_t& seed, const DevMaterial& m, v3 N, v3 V, v3& L
 }
 
 // disney.h:32-46
-PT_HD float disney_pdf(const DevMaterial& m, v3 N, v3 L, v3 H) {
+PT_HD_BRDF float disney_pdf(const DevMaterial& m, v3 N, v3 L, v3 H) {
   float specularRatio = 1.f - m.diffuseRatio;
   float cosTheta = __builtin_fabsf(dot(N, H));
   float pdfGTR1 = GTR1_cc(cosTheta, m) * cosTheta;
@@ -95,7 +95,7 @@ PT_HD float disney_pdf(const DevMaterial& m, v3 N, v3 L, v3 H) {
 }
 
 // disney.h:48-91
-PT_HD v3 disney_eval(const DevMaterial& m, v3 N, v3 L, v3 V, v3 H) {
+PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 N, v3 L, v3 V, v3 H) {
   Onb onb = make_onb(N);
   float NdotL = dot(N, L), NdotV = dot(N, V), NdotH = dot(N, H), LdotH = dot(L, H);
   const v3 one = mk3(1.f, 1.f, 1.f);

@@ -21,9 +21,15 @@
 #if defined(__HIPCC__)
 #define PT_HD __host__ __device__ __forceinline__
 #define PT_D __device__ __forceinline__
+#if defined(PT_OUTLINE_BRDF)
+#define PT_HD_BRDF static __host__ __device__ __attribute__((noinline))
+#else
+#define PT_HD_BRDF PT_HD
+#endif
 #else
 #define PT_HD inline
 #define PT_D inline
+#define PT_HD_BRDF inline
 #endif
 
 namespace pt {

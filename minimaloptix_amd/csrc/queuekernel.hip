@@ -1,0 +1,434 @@
+// queuekernel.hip -- megakernel variants 2 and 3: slot-resident traversal state + stage queues.
+//
+// Measured on variant 1 (coffee, 32 spp): a wave spends 42 % of its time in BVH node steps that
+// run with 34 of 64 lanes, 22 % in leaf passes that run with 18 lanes, 11 % setting rays up for a
+// quarter of the lanes.  The lanes are idle because a lane *owns* its ray: when the ray is parked
+// at a leaf or finished, the lane waits.  Here nothing is owned by a lane.  Path slots hold the
+// complete state in LDS (ray, 1/d, traversal registers, traversal stack) and in an HBM record
+// (path payload); the lanes are workers that pick slots off four queues:
+//
+//   Q_NODE  slots standing at an internal BVH node   -> node loop (o, 1/d, tbest, node, sp only)
+//   Q_LEAF  slots standing at a leaf                 -> leaf pass (triangle tests, any-hit)
+//   Q_SHADE slots whose ray finished (hit / shadow)  -> closest-hit shading, NEE, next ray set-up
+//   Q_GEN   slots needing a new (pixel,sample) item  -> miss, camera ray
+//
+// A lane in the node loop that reaches a leaf or finishes its ray swaps: it stores (node, sp),
+// queues the slot and pops the next slot from Q_NODE.  Leaf passes, shading and regeneration run
+// as 64-wide batches when a queue fills up (or when the node loop starves).  This is the
+// wave-level ray compaction + sorting by stage of the north star; the per-path arithmetic is the
+// same pt_path.h code as variants 0/1, so the images are bit-identical.
+//
+//   variant 2 (SHARED = false): every wave has its own 128 slots and queues (wave-synchronous).
+//   variant 3 (SHARED = true):  the 4 waves of a workgroup share 512 slots and one set of queues
+//       (a spin-lock in LDS guards one short queue transaction per pass), so that full batches
+//       of every stage are available almost all the time.
+#include <hip/hip_runtime.h>
+
+#include "megakernel.h"
+#include "pt_path.h"
+
+namespace pt {
+
+namespace {
+
+constexpr int kBlockThreads = 256;
+constexpr int kWaves = kBlockThreads / 64;
+constexpr int kP = 128;                 // slots per wave
+constexpr int kStackN = 12;             // LDS stack entries per slot; deeper levels spill to HBM
+
+enum { Q_NODE = 0, Q_LEAF = 1, Q_SHADE = 2, Q_GEN = 3, kNumQ = 4, DEST_DONE = 4, DEST_NONE = -1 };
+
+struct alignas(16) SlotCold {           // 6 x 16 B, HBM, private to the pool
+  int mode, pixel, item, depth;
+  uint32_t seed; float thrx, thry, thrz;
+  float radx, rady, radz; int mat;
+  float Nx, Ny, Nz; int light;
+  float Vx, Vy, Vz; float pendInv;
+  float pwx, pwy, pwz; int pad0;
+};
+static_assert(sizeof(SlotCold) == 96, "SlotCold layout");
+
+struct alignas(16) i4 { int x, y, z, w; };
+
+// LDS image of NS slots
+template <int NS>
+struct PoolLds {
+  v4 rayA[NS];            // o.xyz, tmax
+  v4 rayB[NS];            // d.xyz, kind
+  v4 trvA[NS];            // 1/d, tbest
+  i4 trvB[NS];            // node, sp, bestTri, bestPrim
+  v4 trvC[NS];            // beta|att.x, gamma|att.y, att.z, -
+  int stack[NS][kStackN];
+  unsigned short queue[kNumQ][NS];
+  int qHead[kNumQ], qCount[kNumQ];   // SHARED only
+  int done, lock;                    // SHARED only
+};
+
+template <int NS>
+struct WavePriv {
+  unsigned short qnode[NS];        // node-ready slots owned by this wave (ring)
+  unsigned short outbox[3][128];   // slots on their way to the pool's Q_LEAF / Q_SHADE / Q_GEN
+};
+
+struct SlotStack {
+  int* lds;               // &stack[slot][0]
+  int* ovf;               // this slot's overflow area in HBM (or nullptr)
+  __device__ __forceinline__ void store(int sp, int v) {
+    if (sp < kStackN) lds[sp] = v; else ovf[sp - kStackN] = v;
+  }
+  __device__ __forceinline__ int load(int sp) const { return sp < kStackN ? lds[sp] : ovf[sp - kStackN]; }
+};
+
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// destination queue of a slot after a traversal step / a ray set-up
+__device__ __forceinline__ int route(int node, int kind, int bestPrim) {
+  if (node == kTravDone) return (kind == RK_SHADOW || bestPrim >= 0) ? Q_SHADE : Q_GEN;
+  return node >= 0 ? Q_NODE : Q_LEAF;
+}
+
+template <bool CNT, bool SHARED>
+__global__ void __launch_bounds__(kBlockThreads) pt_queuekernel(const LaunchArgs a) {
+  constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
+  __shared__ PoolLds<NS> sPool[SHARED ? 1 : kWaves];
+  __shared__ WavePriv<NS> sPriv[kWaves];
+
+  const SceneView& sc = a.scene;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  PoolLds<NS>& W = sPool[SHARED ? 0 : wave];
+  const int gpool = SHARED ? blockIdx.x : blockIdx.x * kWaves + wave;
+  SlotCold* cold = reinterpret_cast<SlotCold*>(a.poolCold) + (size_t)gpool * NS;
+  int* ovfBase = a.stackOverflow ? a.stackOverflow + (size_t)gpool * NS * a.ovfDepth : nullptr;
+
+  // queue bookkeeping: registers (wave-uniform); with SHARED they mirror LDS inside a transaction
+  int qHead[kNumQ] = { 0, 0, 0, 0 }, qCount[kNumQ] = { 0, 0, 0, 0 };
+  int nDone = 0;
+
+  [[maybe_unused]] auto q_push = [&](int q, bool pred, int slot) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return;
+    if (pred) W.queue[q][(qHead[q] + qCount[q] + lane_rank(m)) & (NS - 1)] = (unsigned short)slot;
+    qCount[q] += __popcll(m);
+  };
+  auto q_pop = [&](int q, bool want) -> int {
+    const unsigned long long m = __ballot(want);
+    const int n = min(__popcll(m), qCount[q]);
+    int slot = -1;
+    if (want) { const int r = lane_rank(m); if (r < n) slot = W.queue[q][(qHead[q] + r) & (NS - 1)]; }
+    qHead[q] = (qHead[q] + n) & (NS - 1);
+    qCount[q] -= n;
+    return slot;
+  };
+  auto txn_begin = [&]() {
+    if constexpr (SHARED) {
+      if (lane == 0) { while (atomicCAS(&W.lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1); }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      for (int q = 0; q < kNumQ; q++) {
+        qHead[q] = __builtin_amdgcn_readfirstlane(W.qHead[q]);
+        qCount[q] = __builtin_amdgcn_readfirstlane(W.qCount[q]);
+      }
+      nDone = __builtin_amdgcn_readfirstlane(W.done);
+    }
+  };
+  auto txn_end = [&]() {
+    if constexpr (SHARED) {
+      if (lane == 0) {
+        for (int q = 0; q < kNumQ; q++) { W.qHead[q] = qHead[q]; W.qCount[q] = qCount[q]; }
+        W.done = nDone;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&W.lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+  auto make_stack = [&](int slot) {
+    SlotStack st;
+    st.lds = &W.stack[slot][0];
+    st.ovf = ovfBase ? ovfBase + (size_t)slot * a.ovfDepth : nullptr;
+    return st;
+  };
+
+  // ---- start-up: every slot needs a work item ----
+  {
+    const int first = SHARED ? threadIdx.x : lane, step = SHARED ? kBlockThreads : 64;
+    for (int s = first; s < NS; s += step) {
+      SlotCold c = {};
+      c.mode = M_NEW_PIXEL;
+      cold[s] = c;
+      W.queue[Q_GEN][s] = (unsigned short)s;
+    }
+    if constexpr (SHARED) {
+      if (threadIdx.x == 0) {
+        for (int q = 0; q < kNumQ; q++) { W.qHead[q] = 0; W.qCount[q] = 0; }
+        W.qCount[Q_GEN] = NS; W.done = 0; W.lock = 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+    } else {
+      qCount[Q_GEN] = NS;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+  }
+
+  Counters ct = {};
+  uint32_t nodeSteps = 0, nodeLanes = 0, leafPasses = 0, leafLanes = 0, batches = 0, batchLanes = 0, idleSpins = 0;
+  unsigned long long tBatch = 0, tSwap = 0, tNode = 0, tLeaf = 0, tStamp = 0;
+  const unsigned long long tStart = CNT ? __builtin_amdgcn_s_memtime() : 0ull;
+#define PT_STAMP(acc) do { if (CNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tStamp; tStamp = now_; } } while (0)
+  tStamp = tStart;
+
+  // ---- node-loop worker context: the only per-lane state that survives between passes ----
+  int ns = -1;                 // slot this lane is walking, -1 = none
+  PathState nray;              // o, tmin used
+  nray.o = mk3(0, 0, 0); nray.tmin = sc.epsT; nray.d = mk3(0, 0, 1); nray.tmax = 0; nray.kind = RK_RADIANCE; nray.mode = M_TRACE;
+  Trav ntv;                    // inv, tbest, node, sp used
+  ntv.node = kTravDone; ntv.sp = 0; ntv.tbest = 0; ntv.inv = mk3(0, 0, 0); ntv.bestPrim = -1; ntv.bestTri = -1;
+  ntv.beta = 0; ntv.gamma = 0; ntv.att = mk3(1, 1, 1); ntv.started = 1;
+
+  // result of the last pass, queued inside the next transaction
+  int pendSlot = -1, pendDest = DEST_NONE;
+
+  // ---- leaf pass: the slots popped from Q_LEAF stand at a leaf ----
+  auto leaf_pass = [&](int slot) {
+    const bool have = slot >= 0;
+    if (CNT) { leafPasses++; leafLanes += (uint32_t)__popcll(__ballot(have)); }
+    pendSlot = slot; pendDest = DEST_NONE;
+    if (have) {
+      PathState ps; Trav tv;
+      ps.tmin = sc.epsT; ps.mode = M_TRACE;
+      const v4 ra = W.rayA[slot], rb = W.rayB[slot], ta = W.trvA[slot], tc = W.trvC[slot];
+      const i4 tb = W.trvB[slot];
+      ps.o = mk3(ra.x, ra.y, ra.z); ps.tmax = ra.w; ps.d = mk3(rb.x, rb.y, rb.z); ps.kind = f2i(rb.w);
+      tv.inv = mk3(ta.x, ta.y, ta.z); tv.tbest = ta.w;
+      tv.node = tb.x; tv.sp = tb.y; tv.bestTri = tb.z; tv.bestPrim = tb.w;
+      tv.beta = tc.x; tv.gamma = tc.y; tv.att = mk3(tc.x, tc.y, tc.z);
+      SlotStack st = make_stack(slot);
+      trav_leaf_step<CNT>(sc, ps, tv, st, ct);
+      W.trvA[slot].w = tv.tbest;
+      i4 nb; nb.x = tv.node; nb.y = tv.sp; nb.z = tv.bestTri; nb.w = tv.bestPrim;
+      W.trvB[slot] = nb;
+      v4 nc;
+      if (ps.kind == RK_SHADOW) { nc.x = tv.att.x; nc.y = tv.att.y; nc.z = tv.att.z; } else { nc.x = tv.beta; nc.y = tv.gamma; nc.z = 0.f; }
+      nc.w = 0.f;
+      W.trvC[slot] = nc;
+      pendDest = route(tv.node, ps.kind, tv.bestPrim);
+    }
+  };
+
+  // ---- shading / regeneration batch: run the path state machine for the popped slots ----
+  auto run_batch = [&](int slot, bool shadeBatch) {
+    const bool have = slot >= 0;
+    if (CNT) { batches++; batchLanes += (uint32_t)__popcll(__ballot(have)); }
+    pendSlot = slot; pendDest = DEST_NONE;
+    PathState ps; Trav res;
+    ps.mode = M_DONE; ps.kind = RK_RADIANCE;
+    res.node = kTravDone; res.bestPrim = -1;
+    if (have) {
+      const SlotCold c = cold[slot];
+      const v4 ra = W.rayA[slot], rb = W.rayB[slot], ta = W.trvA[slot], tc = W.trvC[slot];
+      const i4 tb = W.trvB[slot];
+      ps.mode = c.mode; ps.pixel = c.pixel; ps.item = c.item; ps.depth = c.depth; ps.seed = c.seed;
+      ps.thr = mk3(c.thrx, c.thry, c.thrz); ps.rad = mk3(c.radx, c.rady, c.radz); ps.mat = c.mat;
+      ps.N = mk3(c.Nx, c.Ny, c.Nz); ps.light = c.light; ps.V = mk3(c.Vx, c.Vy, c.Vz); ps.pendInv = c.pendInv;
+      ps.pendW = mk3(c.pwx, c.pwy, c.pwz); ps.accum = mk3(0, 0, 0);
+      ps.o = mk3(ra.x, ra.y, ra.z); ps.tmax = ra.w; ps.d = mk3(rb.x, rb.y, rb.z); ps.kind = f2i(rb.w); ps.tmin = sc.epsT;
+      res.tbest = ta.w; res.bestTri = tb.z; res.bestPrim = tb.w;
+      res.beta = tc.x; res.gamma = tc.y; res.att = mk3(tc.x, tc.y, tc.z);
+      if (ps.mode == M_TRACE) ps.mode = M_RESULT;
+    }
+    for (;;) {
+      if (have && ps.mode == M_NEW_SAMPLE) { store_sample(a, ps.item, ps.accum); ps.mode = M_NEW_PIXEL; }
+      const bool run = have && ps.mode != M_TRACE && ps.mode != M_DONE && !(shadeBatch && ps.mode == M_NEW_PIXEL);
+      if (__ballot(run) == 0ull) break;
+      if (run) {
+        if (ps.mode == M_RESULT) {
+          on_result<CNT>(sc, ps, res, ct);
+        } else if (ps.mode == M_LIGHTS) {
+          on_lights<CNT>(sc, ps, ct);
+        } else {  // M_NEW_PIXEL: next (pixel, sample) work item
+          const int k = atomicAdd(a.workCounter, 1);
+          int s;
+          if (k >= a.nWork) { ps.mode = M_DONE; }
+          else if (item_to_pixel(a, k, s, ps.pixel)) { ps.item = k; begin_sample<CNT>(sc, ps, a.seeds[s], ct); }
+        }
+      }
+    }
+    if (have) {
+      SlotCold c;
+      c.mode = ps.mode; c.pixel = ps.pixel; c.item = ps.item; c.depth = ps.depth; c.seed = ps.seed;
+      c.thrx = ps.thr.x; c.thry = ps.thr.y; c.thrz = ps.thr.z; c.radx = ps.rad.x; c.rady = ps.rad.y; c.radz = ps.rad.z; c.mat = ps.mat;
+      c.Nx = ps.N.x; c.Ny = ps.N.y; c.Nz = ps.N.z; c.light = ps.light; c.Vx = ps.V.x; c.Vy = ps.V.y; c.Vz = ps.V.z; c.pendInv = ps.pendInv;
+      c.pwx = ps.pendW.x; c.pwy = ps.pendW.y; c.pwz = ps.pendW.z; c.pad0 = 0;
+      cold[slot] = c;
+      if (ps.mode == M_TRACE) {
+        // new ray: analytic primitives + traversal set-up happen here, on the full batch
+        Trav tv;
+        trav_begin<CNT>(sc, ps, tv, ct);
+        v4 ra, rb, ta, tc;
+        ra.x = ps.o.x; ra.y = ps.o.y; ra.z = ps.o.z; ra.w = ps.tmax;
+        rb.x = ps.d.x; rb.y = ps.d.y; rb.z = ps.d.z; rb.w = i2f(ps.kind);
+        ta.x = tv.inv.x; ta.y = tv.inv.y; ta.z = tv.inv.z; ta.w = tv.tbest;
+        i4 tb; tb.x = tv.node; tb.y = 0; tb.z = tv.bestTri; tb.w = tv.bestPrim;
+        if (ps.kind == RK_SHADOW) { tc.x = tv.att.x; tc.y = tv.att.y; tc.z = tv.att.z; } else { tc.x = 0.f; tc.y = 0.f; tc.z = 0.f; }
+        tc.w = 0.f;
+        W.rayA[slot] = ra; W.rayB[slot] = rb; W.trvA[slot] = ta; W.trvB[slot] = tb; W.trvC[slot] = tc;
+        pendDest = route(tv.node, ps.kind, tv.bestPrim);
+      } else if (ps.mode == M_NEW_PIXEL) {
+        pendDest = Q_GEN;
+      } else {
+        pendDest = DEST_DONE;
+      }
+    }
+  };
+
+  // per-wave private structures: the node-ready ring (slots produced by this wave's own passes
+  // stay with the wave) and the out-boxes that collect slots for the pool-wide queues between
+  // two transactions
+  unsigned short* myNodeQ = sPriv[wave].qnode;
+  int nqHead = 0, nqCount = 0;
+  int obCount[3] = { 0, 0, 0 };            // out-boxes for Q_LEAF, Q_SHADE, Q_GEN
+  int localDone = 0;
+  auto local_push = [&](int dest, int slot) {   // wave-collective; dest per lane
+    {
+      const unsigned long long m = __ballot(dest == Q_NODE);
+      if (m != 0ull) {
+        if (dest == Q_NODE) myNodeQ[(nqHead + nqCount + lane_rank(m)) & (NS - 1)] = (unsigned short)slot;
+        nqCount += __popcll(m);
+      }
+    }
+    for (int d = 0; d < 3; d++) {
+      const unsigned long long m = __ballot(dest == Q_LEAF + d);
+      if (m != 0ull) {
+        if (dest == Q_LEAF + d) sPriv[wave].outbox[d][obCount[d] + lane_rank(m)] = (unsigned short)slot;
+        obCount[d] += __popcll(m);
+      }
+    }
+    localDone += __popcll(__ballot(dest == DEST_DONE));
+  };
+
+  unsigned int guard = 0;
+  for (;;) {
+    if (++guard > (1u << 27)) { if (lane == 0) atomicOr(a.workCounter + 1, 1); break; }   // bounded: never hang the GPU
+    // ---- local bookkeeping (no lock): results of the last pass, swap, refill ----
+    if (__ballot(pendDest != DEST_NONE) != 0ull) { local_push(pendDest, pendSlot); pendDest = DEST_NONE; }
+    {
+      const bool leave = ns >= 0 && !(ntv.node >= 0 && ntv.node != kTravDone);
+      if (__ballot(leave) != 0ull) {
+        int dest = DEST_NONE;
+        if (leave) {
+          W.trvB[ns].x = ntv.node; W.trvB[ns].y = ntv.sp;
+          dest = route(ntv.node, ntv.node == kTravDone ? f2i(W.rayB[ns].w) : RK_RADIANCE, ntv.node == kTravDone ? W.trvB[ns].w : -1);
+        }
+        local_push(dest, ns);
+        if (leave) ns = -1;
+      }
+      if (nqCount > 0 && __ballot(ns < 0) != 0ull) {
+        const unsigned long long m = __ballot(ns < 0);
+        const int n = min(__popcll(m), nqCount);
+        if (ns < 0) {
+          const int r = lane_rank(m);
+          if (r < n) {
+            ns = myNodeQ[(nqHead + r) & (NS - 1)];
+            const v4 ra = W.rayA[ns], ta = W.trvA[ns];
+            nray.o = mk3(ra.x, ra.y, ra.z);
+            ntv.inv = mk3(ta.x, ta.y, ta.z); ntv.tbest = ta.w;
+            ntv.node = W.trvB[ns].x; ntv.sp = W.trvB[ns].y;
+          }
+        }
+        nqHead = (nqHead + n) & (NS - 1); nqCount -= n;
+      }
+    }
+    const int nActive = __popcll(__ballot(ns >= 0));
+    const bool starving = nActive <= 64 - a.starveLanes;
+    int pass = -1;      // -1 node loop, 0 leaf, 1 shade, 2 gen, 3 idle, 4 exit
+    int mySlot = -1;
+    if (starving || obCount[0] >= 32 || obCount[1] >= 32 || obCount[2] >= 32) {
+      // =========================== queue transaction ===========================
+      txn_begin();
+      for (int d = 0; d < 3; d++) {
+        const int q = Q_LEAF + d;
+        for (int base = 0; base < obCount[d]; base += 64) {
+          const int i = base + lane;
+          if (i < obCount[d]) W.queue[q][(qHead[q] + qCount[q] + i) & (NS - 1)] = sPriv[wave].outbox[d][i];
+        }
+        qCount[q] += obCount[d]; obCount[d] = 0;
+      }
+      nDone += localDone; localDone = 0;
+      if (qCount[Q_SHADE] >= 64) pass = 1;
+      else if (qCount[Q_GEN] >= 64) pass = 2;
+      else if (qCount[Q_LEAF] >= 64) pass = 0;
+      else if (starving) {
+        const int l = qCount[Q_LEAF], sh = qCount[Q_SHADE], g = qCount[Q_GEN];
+        if (l + sh + g == 0) { if (nActive == 0) pass = (nDone == NS) ? 4 : 3; }
+        else pass = (l >= sh && l >= g) ? 0 : (sh >= g ? 1 : 2);
+      }
+      if (pass >= 0 && pass <= 2) mySlot = q_pop(pass == 0 ? Q_LEAF : (pass == 1 ? Q_SHADE : Q_GEN), true);
+      txn_end();
+      // =========================================================================
+    }
+    PT_STAMP(tSwap);
+    if (pass == 4) break;
+    if (pass == 3) { if (CNT) idleSpins++; __builtin_amdgcn_s_sleep(32); continue; }
+    if (pass == 0) { leaf_pass(mySlot); PT_STAMP(tLeaf); continue; }
+    if (pass > 0) { run_batch(mySlot, pass == 1); PT_STAMP(tBatch); continue; }
+
+    // ---- node loop: until swapLanes lanes have left the node set ----
+    {
+      SlotStack st = make_stack(ns >= 0 ? ns : 0);
+      for (;;) {
+        const bool atNode = ns >= 0 && ntv.node >= 0 && ntv.node != kTravDone;
+        const unsigned long long m = __ballot(atNode);
+        const int n = __popcll(m);
+        if (n == 0 || nActive - n >= a.swapLanes) break;
+        if (CNT) { nodeSteps++; nodeLanes += (uint32_t)n; }
+        if (atNode) trav_node_step<CNT>(sc, nray, ntv, st, ct);
+      }
+    }
+    PT_STAMP(tNode);
+  }
+
+  if constexpr (CNT) {
+    unsigned long long* c = a.counters;
+    const uint32_t v[9] = { wave_sum(ct.samples), wave_sum(ct.primaryRays), wave_sum(ct.bounceRays), wave_sum(ct.shadowRays),
+                            wave_sum(ct.nodeFetches), wave_sum(ct.triTests), wave_sum(ct.closestHits), wave_sum(ct.lightLoads),
+                            wave_sum(ct.analyticTests) };
+    if (lane == 0) {
+      for (int i = 0; i < 9; i++) atomicAdd(&c[i], (unsigned long long)v[i]);
+      atomicAdd(&c[9], (unsigned long long)nodeSteps + leafPasses);
+      atomicAdd(&c[10], (unsigned long long)nodeLanes + leafLanes);
+      atomicAdd(&c[11], (unsigned long long)batches);
+      atomicAdd(&c[12], (unsigned long long)batchLanes);
+      atomicAdd(&c[14], (unsigned long long)idleSpins);
+      atomicAdd(&c[16], tBatch); atomicAdd(&c[17], tSwap); atomicAdd(&c[18], tNode); atomicAdd(&c[19], tLeaf);
+      atomicAdd(&c[21], __builtin_amdgcn_s_memtime() - tStart);
+      atomicAdd(&c[22], (unsigned long long)leafPasses); atomicAdd(&c[23], (unsigned long long)leafLanes);
+    }
+  }
+}
+
+}  // namespace
+
+int queuekernel_lds_stack_entries() { return kStackN; }
+int queuekernel_slots() { return kP; }
+size_t queuekernel_cold_bytes(int nBlocks) { return (size_t)nBlocks * kWaves * kP * sizeof(SlotCold); }
+size_t queuekernel_overflow_ints(int nBlocks, int ovfDepth) { return (size_t)nBlocks * kWaves * kP * (size_t)ovfDepth; }
+
+hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool shared, bool counted) {
+  dim3 grid(nBlocks), block(kBlockThreads);
+  if (shared) {
+    if (counted) pt_queuekernel<true, true><<<grid, block, 0, stream>>>(a);
+    else         pt_queuekernel<false, true><<<grid, block, 0, stream>>>(a);
+  } else {
+    if (counted) pt_queuekernel<true, false><<<grid, block, 0, stream>>>(a);
+    else         pt_queuekernel<false, false><<<grid, block, 0, stream>>>(a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace pt

@@ -43,6 +43,51 @@ def test_render_matches_oracle(gpu_ctx, kind, kw, res, spp):
     assert np.array_equal(gpu_ctx.accum_read(), g)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_all_kernel_variants_are_bit_identical(gpu_ctx, variant):
+    """The four schedulers (per-lane, per-wave pool, slot queues, workgroup-shared queues) run the
+    same per-path arithmetic: identical images, identical ray counts, and parity with the oracle."""
+    hs = M.HostScene("file:coffee", 200, 112)
+    seeds = M.launch_seeds(3)
+    default = gpu_ctx.get_option("kernel_variant")
+    try:
+        gpu_ctx.set_option("kernel_variant", variant)
+        gpu_ctx.load(hs)
+        gpu_ctx.accum_clear()
+        st = gpu_ctx.render_counted(seeds)
+        g = gpu_ctx.accum_read()
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(seeds)
+        g2 = gpu_ctx.accum_read()
+    finally:
+        gpu_ctx.set_option("kernel_variant", default)
+    o, ost = oracle_scene(hs).render(seeds)
+    assert np.array_equal(g, g2)
+    assert rmse(g / 3, o / 3) <= RMSE_TIGHT
+    assert st.rays == ost.rays and st.closestHits == ost.closestHits
+    gpu_ctx.set_option("kernel_variant", 0)
+    gpu_ctx.load(hs); gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+    ref = gpu_ctx.accum_read()
+    gpu_ctx.set_option("kernel_variant", default)
+    assert np.array_equal(g, ref)
+
+
+def test_render_in_passes_equals_single_pass(gpu_ctx):
+    """A batch that does not fit the per-sample buffer is cut into passes of whole launches;
+    the ordered reduction keeps the result bit-identical."""
+    hs = M.HostScene("spheres", 160, 90, farg=0.5)
+    seeds = M.launch_seeds(7)
+    gpu_ctx.load(hs)
+    gpu_ctx.accum_clear(); gpu_ctx.render(seeds); a = gpu_ctx.accum_read()
+    mb = gpu_ctx.get_option("sample_buffer_mb")
+    try:
+        gpu_ctx.set_option("sample_buffer_mb", 1)     # 160x90x12 B = 0.17 MB per launch -> 5+2
+        gpu_ctx.accum_clear(); gpu_ctx.render(seeds); b = gpu_ctx.accum_read()
+    finally:
+        gpu_ctx.set_option("sample_buffer_mb", mb)
+    assert np.array_equal(a, b)
+
+
 def test_launch_by_launch_equals_fused(gpu_ctx):
     """nSeeds moptix_launch calls (MinimalOptiX.cpp:544-546) == one fused moptix_render."""
     hs = M.HostScene("spheres", 96, 54, farg=0.5)
