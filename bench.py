@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json headline benchmark of the MinimalOptiX render path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one frame of the metric's configuration: coffee.obj scene (168,193 triangles, LBVH),
+1920x1080, 256 spp = clear + 256 fused launches of the megakernel + ordered sample reduction
+(+ for N > 1 the RCCL gather of the tile-partitioned framebuffer to rank 0).  Scene, BVH and
+seeds are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
+
+
+def algorithmic_bytes(st, pixels):
+    """B = 64*N_node + 48*N_tri + 108*N_hit + 72*N_lightLoads + 24*N_accum.
+    N_accum is counted per pixel per launch batch (the per-sample buffer traffic is not claimed)."""
+    return 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * pixels
+
+
+def cpu_baseline(width, height, n_launches):
+    """The CPU oracle (kind "port": this repo's plain-C restatement; the reference has no CPU path),
+    all host cores, on a bounded sample of the same workload: the full frame for the first
+    `n_launches` of the 256 launch seeds."""
+    from oracle import oracle as O
+    import minimaloptix_amd as M
+    hs = M.HostScene("file:coffee", width, height)
+    sc = O.Scene(hs.to_dict())
+    seeds = M.launch_seeds(n_launches)
+    t0 = time.time()
+    _, st = sc.render(seeds)
+    dt = time.time() - t0
+    return {"value": round(st.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": int(O.lib().orc_num_threads()), "kind": "port",
+            "sample": "coffee %dx%d, %d of 256 launches (%.1f s, %d rays, BVH build included)" % (width, height, n_launches, dt, st.rays)}
+
+
+def read_traffic(repo):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (collected separately, see
+    profiles/README.md); None when absent."""
+    p = os.path.join(repo, "profiles", "traffic.json")
+    try:
+        return json.load(open(p)).get("traffic_GB_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--scene", default="file:coffee")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-launches", type=int, default=8)
+    a = ap.parse_args()
+
+    import torch
+    import minimaloptix_amd as M
+    from minimaloptix_amd import dist as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    dev = torch.device("cuda", local)
+    ctx = M.Context(local)                      # raises when the HIP library / device is missing: no fallback
+    hs = M.HostScene(a.scene, a.width, a.height)
+    ctx.set_partition(rank, world)
+    ctx.load(hs)
+    info = ctx.accel_info()
+    W, H = a.width, a.height
+    accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    ctx.accum_bind(accum.data_ptr())
+    seeds = M.launch_seeds(a.spp)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # counting launch (untimed): rays and algorithmic bytes of one frame are deterministic
+    accum.zero_(); torch.cuda.synchronize()
+    st = ctx.render_counted(seeds)
+    my_pixels = len(D.tile_pixel_indices(W, H, rank, world))
+    my_rays, my_bytes = st.rays, algorithmic_bytes(st, my_pixels)
+    tot = torch.tensor([float(my_rays), float(my_bytes)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot)
+    total_rays, total_bytes = float(tot[0].item()), float(tot[1].item())
+
+    def step():
+        accum.zero_()
+        torch.cuda.synchronize()
+        ctx.render(seeds)                                           # blocking: launches + ordered reduction
+        return D.gather_tiles(accum.view(H * W, 3), W, H, rank, world, dst=0) if world > 1 else None
+
+    for _ in range(a.warmup):
+        step()
+    ctx.kernel_time(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    kms, nlaunch = ctx.kernel_time()
+    reduce_ms = ctx.reduce_time()
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        launch_ms = kms / max(1, nlaunch)
+        passes_per_step = max(1, nlaunch // max(1, a.steps))
+        achieved = my_bytes / passes_per_step / (launch_ms * 1e-3) / 1e9          # GB/s, rank 0's trace kernel
+        out = {
+            "metric": "Mrays/s (primary+bounce+shadow rays traced per second, coffee.obj 1920x1080 256spp)",
+            "value": round(total_rays / (dt / a.steps) / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "reference scene scenes/coffee (168,193 triangles; Mesh010 missing upstream), synthetic seed schedule tea16(i,0)",
+            "config": {"workload": "coffee.obj LBVH build+traverse, %dx%d, %d spp (BASELINE.json configs[2])" % (W, H, a.spp),
+                       "scene": a.scene, "width": W, "height": H, "spp": a.spp, "rays_per_frame": int(total_rays),
+                       "parallelism": "tile-split x%d + RCCL gather" % world if world > 1 else "single GPU",
+                       "kernel_variant": ctx.get_option("kernel_variant"), "bvh_nodes": int(info.nNodes), "bvh_depth": int(info.treeDepth),
+                       "bvh_build_ms": round(float(info.buildMs), 3), "ms_per_frame": round(ms_per_step, 3)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": read_traffic(REPO),
+                         "kernel": "pt_queuekernel (trace)", "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
+                         "algorithmic_bytes_per_launch": int(my_bytes // passes_per_step),
+                         "bytes_per_ray": round(my_bytes / max(1, my_rays), 1), "reduce_ms_total": round(reduce_ms, 3)},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(W, H, a.cpu_launches)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+"""Multi-GPU plumbing (new relative to the reference): one process per GPU,
+torch.distributed over RCCL ("nccl") or gloo.  Nothing here is on the per-ray path.
+
+  tile split   : every rank renders the 8x8-pixel tiles t (raster order) with t % N == rank
+                 (moptix_set_partition); per-pixel seeds depend only on the global pixel index
+                 and the launch seed, so the gathered frame is bit-identical to a 1-GPU frame.
+                 One exchange at the end: gather of the packed tiles to rank 0.
+  sample split : every rank renders the whole frame for launches i with i % N == rank; one
+                 reduce(sum) of the accumulators (equal to 1-GPU up to float summation order).
+"""
+import numpy as np
+
+
+def tile_pixel_indices(width, height, rank, nranks):
+    """Global pixel ids (y*W+x, row 0 = bottom) owned by `rank`, in work-item order."""
+    tiles_x, tiles_y = (width + 7) // 8, (height + 7) // 8
+    t = np.arange(rank, tiles_x * tiles_y, nranks, dtype=np.int64)
+    tx, ty = t % tiles_x, t // tiles_x
+    inn = np.arange(64, dtype=np.int64)
+    x = (tx[:, None] * 8 + (inn & 7)[None, :]).reshape(-1)
+    y = (ty[:, None] * 8 + (inn >> 3)[None, :]).reshape(-1)
+    ok = (x < width) & (y < height)
+    return (y * width + x)[ok]
+
+
+def max_tile_pixels(width, height, nranks):
+    return max(len(tile_pixel_indices(width, height, r, nranks)) for r in range(nranks))
+
+
+def gather_tiles(accum, width, height, rank, nranks, dst=0, group=None):
+    """accum: torch tensor [H*W, 3] (or [H, W, 3]) holding this rank's tiles (others untouched).
+    Returns the assembled [H, W, 3] frame on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    flat = accum.reshape(-1, 3)
+    if nranks == 1:
+        return flat.reshape(height, width, 3)
+    idx = [torch.from_numpy(tile_pixel_indices(width, height, r, nranks)).to(flat.device) for r in range(nranks)]
+    nmax = max(len(i) for i in idx)
+    send = torch.zeros((nmax, 3), dtype=flat.dtype, device=flat.device)
+    send[:len(idx[rank])] = flat[idx[rank]]
+    if rank == dst:
+        recv = [torch.empty_like(send) for _ in range(nranks)]
+        try:
+            dist.gather(send, recv, dst=dst, group=group)
+        except (RuntimeError, NotImplementedError):     # backend without gather: fall back to all_gather
+            dist.all_gather(recv, send, group=group)
+        frame = torch.zeros((height * width, 3), dtype=flat.dtype, device=flat.device)
+        for r in range(nranks):
+            frame[idx[r]] = recv[r][:len(idx[r])]
+        return frame.reshape(height, width, 3)
+    try:
+        dist.gather(send, None, dst=dst, group=group)
+    except (RuntimeError, NotImplementedError):
+        dist.all_gather([torch.empty_like(send) for _ in range(nranks)], send, group=group)
+    return None
+
+
+def sample_split_seeds(seeds, rank, nranks):
+    """Launches i with i % N == rank (SURVEY 8d seed schedule)."""
+    return np.asarray(seeds)[rank::nranks]
+
+
+def reduce_frame(accum, dst=0, group=None):
+    """Sample split: sum of the per-rank accumulators on `dst`."""
+    import torch.distributed as dist
+    dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return accum

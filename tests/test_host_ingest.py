@@ -1,0 +1,117 @@
+"""Host-side ingest kept from the reference: .obj loader, .scene parser, scene builders."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from common import M
+
+K = M._capi
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KAT = json.load(open(os.path.join(GOLD, "kat.json")))
+
+
+def _obj_stats(path):
+    nv, nn, nt, ns = (C.c_int32() for _ in range(4))
+    faces = K.host_lib().mohost_obj_stats(path.encode(), C.byref(nv), C.byref(nn), C.byref(nt), C.byref(ns))
+    return faces, nv.value, nn.value, nt.value, ns.value
+
+
+def test_obj_loader_matches_reference_mesh_inventory():
+    """SURVEY A3 inventory, measured there with the reference's vendored tiny_obj_loader."""
+    total_f = total_v = 0
+    for name, (verts, faces) in KAT["coffee_meshes"].items():
+        f, nv, nn, nt, ns = _obj_stats(os.path.join(M.scenes_dir(), "coffee", name + ".obj"))
+        assert (f, nv, ns) == (faces, verts, 1) and nn == verts and nt == verts, name
+        total_f += f; total_v += nv
+    assert (total_f, total_v) == (168193, 101812)
+
+
+def test_obj_loader_syntax(tmp_path):
+    p = tmp_path / "t.obj"
+    p.write_text("# comment\nmtllib x.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0.5 0.5\n"
+                 "g quad\nf 1/1/1 2/1/1 3/1/1 4/1/1\n"          # quad -> fan of 2 triangles
+                 "o tri\nusemtl m\nf -4//1 -3//1 -2//1\n"       # negative indices, v//vn form
+                 "f 1 2 3\n")                                   # bare vertex form, same shape
+    f, nv, nn, nt, ns = _obj_stats(str(p))
+    assert (f, nv, nn, nt, ns) == (4, 4, 1, 1, 2)
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nf 1 2 3\n")                         # indices out of range are kept as-is by tinyobj too
+    assert _obj_stats(str(tmp_path / "missing.obj"))[0] == -1
+    assert "Cannot open file" in K.host_lib().mohost_last_error().decode()
+
+
+def test_coffee_scene_file():
+    hs = M.HostScene("file:coffee", 1920, 1080)
+    s = hs.sizes
+    assert (s.nFaces, s.nVerts, s.nMeshes, s.nLights, s.nQuads, s.nSpheres) == (168193, 101812, 19, 3, 3, 0)
+    assert hs.accel == "Trbvh" and len(hs.warnings) == 1 and "Mesh010.obj" in hs.warnings[0]
+    assert np.allclose(hs.aabb_min, [-1, 0, -1.094168], atol=1e-6) and np.allclose(hs.aabb_max, [1, 0.811135, 1], atol=1e-6)
+    d = hs.to_dict()
+    k = KAT["cam_coffee"]
+    for f in ("origin", "horizontal", "vertical", "scrLowerLeftCorner", "u", "v"):
+        assert np.allclose(d["cam"][f], k[f], atol=2e-6), f
+    assert d["bgColor"] == [0, 0, 0] and d["rayMaxDepth"] == 256 and abs(d["rayEpsilonT"] - 1e-3) < 1e-9
+    mats = d["materials"]
+    floor = [m for m in mats if m["kind"] == K.MAT_DISNEY and np.allclose(m["color"], [0.578] * 3)]
+    assert floor and abs(floor[0]["roughness"] - 0.01) < 1e-7 and floor[0]["specular"] == 0.5 and floor[0]["clearcoatGloss"] == 1.0
+    assert sum(1 for m in mats if m["kind"] == K.MAT_LIGHT) == 3
+    assert all(np.allclose(l["emission"], [4, 4, 4]) and l["shape"] == K.LIGHT_QUAD for l in d["lights"])
+    # scene.cpp:78-83: u=v1-pos, v=v2-pos, area=|u x v|, normal=normalize(u x v)
+    l0 = d["lights"][0]
+    u, v = np.float32(l0["u"]), np.float32(l0["v"])
+    assert np.isclose(l0["area"], np.linalg.norm(np.cross(u, v)), rtol=1e-5)
+    # light quad geometry uses setQuadParams(position,u,v): its plane normal is MINUS light.normal
+    assert np.allclose(d["quads"][0][:3], -np.float32(l0["normal"]), atol=1e-6)
+
+
+def test_missing_mesh_is_an_error_when_strict():
+    with pytest.raises(M.MoptixError):
+        M.HostScene("file:coffee", 64, 36, skip_missing=False)
+    with pytest.raises(M.MoptixError):
+        M.HostScene("file:nonexistent", 64, 36)
+
+
+def test_scene_parser_quirks(tmp_path):
+    """scene.cpp:5-124: '#' comments, per-line sscanf of every key, brdf enum, quad light derivation,
+    width/height parsed but unused, unknown material name reported and skipped."""
+    d = tmp_path / "scenes" / "mini"
+    d.mkdir(parents=True)
+    (d / "a.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+    (d / "mini.scene").write_text(
+        "# a comment\nproperties\n{\n\twidth 800\n\theight 1000\n}\n"
+        "material Shiny\n{\n\tcolor 0.25 0.5 0.75\n\troughness 0.125\n\tmetallic 1.0\n\tbrdf 1\n\tclearcoat 0.5\n}\n"
+        "mesh\n{\n\tfile a.obj\n\tmaterial Shiny\n}\n"
+        "light\n{\n\ttype Quad\n\tposition 0 2 0\n\tv1 1 2 0\n\tv2 0 2 1\n\temission 3 2 1\n}")
+    # "cornell" selects the camera/background of MinimalOptiX.cpp:323-335; the folder holds our file
+    os.rename(d, tmp_path / "scenes" / "cornell")
+    os.rename(tmp_path / "scenes" / "cornell" / "mini.scene", tmp_path / "scenes" / "cornell" / "cornell.scene")
+    hs = M.HostScene("file:cornell", 128, 72, base_folder=str(tmp_path / "scenes") + "/")
+    dd = hs.to_dict()
+    m = dd["materials"][0]
+    assert m["kind"] == K.MAT_DISNEY and np.allclose(m["color"], [0.25, 0.5, 0.75]) and m["brdfType"] == K.BRDF_GLASS
+    assert m["roughness"] == 0.125 and m["metallic"] == 1.0 and m["clearcoat"] == 0.5 and m["sheenTint"] == 0.5
+    l = dd["lights"][0]
+    assert np.allclose(l["u"], [1, 0, 0]) and np.allclose(l["v"], [0, 0, 1]) and np.isclose(l["area"], 1.0)
+    assert np.allclose(l["normal"], [0, -1, 0]) and np.allclose(l["emission"], [3, 2, 1])
+    assert dd["bgColor"] == [0.5, 0.5, 0.5] and (dd["width"], dd["height"]) == (128, 72)   # .scene width/height ignored
+    assert hs.sizes.nFaces == 1
+
+
+def test_builtin_scenes():
+    s = M.HostScene("spheres", 1920, 1080, farg=0.5)
+    assert (s.sizes.nSpheres, s.sizes.nQuads, s.accel) == (3, 2, "NoAccel")
+    kinds = [m["kind"] for m in s.to_dict()["materials"]]
+    assert kinds == [K.MAT_LAMBERTIAN, K.MAT_METAL, K.MAT_GLASS, K.MAT_LAMBERTIAN, K.MAT_LIGHT]
+    r = M.HostScene("random_spheres", 1280, 720, iarg=497)
+    assert (r.sizes.nSpheres, r.sizes.nQuads) == (500, 33)                    # 3 + 497 spheres, floor + 32 light quads
+    d = r.to_dict()
+    sp = d["spheres"]
+    assert np.allclose(sp[:3, 3], 3.0) and (sp[3:, 3] >= 0.0099).all() and (sp[3:, 3] <= 0.8 + 1e-6).all()
+    assert np.allclose(sp[3:, 1], np.sqrt(sp[3:, 0] ** 2 + sp[3:, 2] ** 2), atol=1e-5)   # y = |(x,z)| (MinimalOptiX.cpp:643-645)
+    r2 = M.HostScene("random_spheres", 1280, 720, iarg=497)
+    assert np.array_equal(r2.to_dict()["spheres"], sp)                                  # deterministic layout (mt19937(42))
+    c = M.HostScene("cornell_quads", 256, 256)
+    assert (c.sizes.nQuads, c.sizes.nSpheres, c.sizes.nFaces) == (16, 0, 0)

@@ -1,0 +1,60 @@
+"""The megakernel's per-lane code compiled for the host (tests/hostsim) against the recursive CPU
+oracle: same paths, same ray counts.  This is what is checked before any GPU time is spent; the
+GPU tests then check that the device runs the same code to the same bits."""
+import numpy as np
+import pytest
+
+from common import M, hostsim_bvh, hostsim_render, oracle_scene, rmse
+
+CASES = [("spheres", dict(farg=0.5), (128, 72), 3), ("cornell_quads", {}, (48, 48), 2),
+         ("random_spheres", dict(iarg=97), (96, 54), 2), ("file:coffee", {}, (96, 54), 2)]
+
+
+@pytest.mark.parametrize("kind,kw,res,spp", CASES)
+def test_flattened_state_machine_equals_recursive_oracle(kind, kw, res, spp):
+    hs = M.HostScene(kind, res[0], res[1], **kw)
+    seeds = M.launch_seeds(spp)
+    o, ost = oracle_scene(hs).render(seeds)
+    h, hc = hostsim_render(hs, seeds)
+    assert rmse(h / spp, o / spp) < 2e-6
+    assert (hc["primaryRays"], hc["bounceRays"], hc["shadowRays"], hc["closestHits"]) == \
+           (ost.primaryRays, ost.bounceRays, ost.shadowRays, ost.closestHits)
+
+
+@pytest.mark.parametrize("leaf", [1, 4, 8])
+def test_lbvh_mirror_is_a_valid_bvh(leaf):
+    hs = M.HostScene("file:coffee", 64, 36)
+    nodes, tris, prim, root, depth = hostsim_bvh(hs, leaf)
+    n = hs.sizes.nFaces
+    assert sorted(prim.tolist()) == list(range(n))                       # every face exactly once
+    assert root == 0 and 10 < depth < 64
+    c = nodes[:, 12:14].view(np.int32)
+    leaves = c[c < 0]
+    first, count = (~leaves) >> 3, ((~leaves) & 7) + 1
+    assert count.max() <= leaf and count.sum() == n
+    covered = np.zeros(n, np.int32)
+    for f, k in zip(first, count):
+        covered[f:f + k] += 1
+    assert (covered == 1).all()                                          # leaves partition the sorted records
+    internal = c[c >= 0]
+    assert len(internal) == len(nodes) - 1 and len(set(internal.tolist())) == len(internal)   # a tree
+    # child boxes contain their triangles (first leaf of every node, spot check)
+    boxes = nodes[:, :12].view(np.float32)
+    p0 = tris[:, 0:3].view(np.float32); e0 = tris[:, 4:7].view(np.float32); e1 = tris[:, 8:11].view(np.float32)
+    for i in range(0, len(nodes), 997):
+        for side, ref in enumerate(c[i]):
+            if ref >= 0:
+                continue
+            lo = boxes[i, 0:3] if side == 0 else boxes[i, 6:9]
+            hi = boxes[i, 3:6] if side == 0 else boxes[i, 9:12]
+            f, k = (~ref) >> 3, ((~ref) & 7) + 1
+            v = np.concatenate([p0[f:f + k], p0[f:f + k] + e0[f:f + k], p0[f:f + k] - e1[f:f + k]])
+            assert (v >= lo - 1e-6).all() and (v <= hi + 1e-6).all()
+
+
+def test_leaf_size_does_not_change_the_image():
+    hs = M.HostScene("file:coffee", 80, 45)
+    seeds = M.launch_seeds(2)
+    a, _ = hostsim_render(hs, seeds, leaf_size=1)
+    b, _ = hostsim_render(hs, seeds, leaf_size=8)
+    assert np.array_equal(a, b)        # equal-t rule makes the hit independent of the tree
