@@ -335,9 +335,16 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
 
 // Disney next-event estimation loop + BRDF bounce (Material.cu:170-221).  Runs until the
 // lane owns a ray again (shadow ray towards light `ps.light`, or the bounce) or the sample ends.
+// The cheap part (light sampling, facing tests, BRDF direction sampling) picks ONE candidate
+// direction per lane; disney_pdf/disney_eval -- the expensive part -- are then evaluated once,
+// for light candidates and bounce candidates together, so a shading batch runs them on a full
+// wave.  Same formulas and the same RNG draw order as the reference's program.
 template <bool CNT>
 PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
   const DevMaterial& m = sc.mats[ps.mat];
+  int choice = 0;                       // 0 nothing, 1 shadow ray towards a light, 2 BRDF bounce
+  v3 L = mk3(0.f, 0.f, 1.f), H = mk3(0.f, 0.f, 1.f), emission = mk3(0.f, 0.f, 0.f);
+  float lightDst = 0.f, lightPdf = 0.f;
   while (ps.light < sc.nLights) {
     const DevLight* lt = sc.lights + ps.light;
     cnt<CNT>(ct.lightLoads);
@@ -350,39 +357,45 @@ PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
       pointOnLight = (lt->position + lt->u * r1) + lt->v * r2;
       normalOnLight = normalize(lt->normal);
     }
-    v3 L = pointOnLight - ps.o;
-    const float lightDst = length(L);
+    L = pointOnLight - ps.o;
+    lightDst = length(L);
     L = normalize(L);
     if (dot(L, ps.N) > 0.f && dot(L, normalOnLight) < 0.f) {
-      const v3 H = normalize(L + ps.V);
-      const float lightPdf = lightDst * lightDst / lt->area / dot(normalOnLight, -L);
-      const float objPdf = disney_pdf(m, ps.N, L, H);
-      if (lightPdf > 0 && objPdf > 0) {
-        const v3 brdf = disney_eval(m, ps.N, L, ps.V, H);
-        ps.pendW = (brdf * powerHeuristic(lightPdf, objPdf)) * lt->emission;
-        ps.pendInv = 1.0f / fmaxf_(0.001f, lightPdf);
-      } else {
-        ps.pendW = mk3(0.f, 0.f, 0.f); ps.pendInv = 0.f;
-      }
-      ps.d = L; ps.tmin = sc.epsT; ps.tmax = lightDst - sc.epsT; ps.kind = RK_SHADOW;
-      ps.mode = M_TRACE;
-      cnt<CNT>(ct.shadowRays);
-      return;
+      H = normalize(L + ps.V);
+      lightPdf = lightDst * lightDst / lt->area / dot(normalOnLight, -L);
+      emission = lt->emission;
+      choice = 1;
+      break;
     }
     ps.light++;
   }
-  v3 L, H;
-  disney_sample(ps.seed, m, ps.N, ps.V, L, H);
-  if (dot(ps.N, L) > 0.0f && dot(ps.N, ps.V) > 0.0f) {
-    const uint32_t childSeed = fork_seed(ps.seed, ps.depth + 1);
-    const float pdf = disney_pdf(m, ps.N, L, H);
-    cnt<CNT>(ct.bounceRays);
-    if (pdf > 0) {
-      const v3 brdf = disney_eval(m, ps.N, L, ps.V, H);
-      ps.thr = (ps.thr * brdf) * (1.0f / pdf);
-      bounce(sc, ps, ps.o, L, childSeed);
-      return;
+  if (choice == 0) {
+    disney_sample(ps.seed, m, ps.N, ps.V, L, H);
+    if (dot(ps.N, L) > 0.0f && dot(ps.N, ps.V) > 0.0f) choice = 2;
+  }
+  if (choice == 0) { end_sample(ps); return; }
+
+  const float pdf = disney_pdf(m, ps.N, L, H);
+  const v3 brdf = disney_eval(m, ps.N, L, ps.V, H);
+
+  if (choice == 1) {
+    if (lightPdf > 0 && pdf > 0) {
+      ps.pendW = (brdf * powerHeuristic(lightPdf, pdf)) * emission;
+      ps.pendInv = 1.0f / fmaxf_(0.001f, lightPdf);
+    } else {
+      ps.pendW = mk3(0.f, 0.f, 0.f); ps.pendInv = 0.f;
     }
+    ps.d = L; ps.tmin = sc.epsT; ps.tmax = lightDst - sc.epsT; ps.kind = RK_SHADOW;
+    ps.mode = M_TRACE;
+    cnt<CNT>(ct.shadowRays);
+    return;
+  }
+  const uint32_t childSeed = fork_seed(ps.seed, ps.depth + 1);
+  if (pdf > 0) {
+    ps.thr = (ps.thr * brdf) * (1.0f / pdf);
+    cnt<CNT>(ct.bounceRays);
+    bounce(sc, ps, ps.o, L, childSeed);
+    return;
   }
   end_sample(ps);
 }

@@ -70,13 +70,22 @@ struct WavePriv {
   unsigned short outbox[3][128];   // slots on their way to the pool's Q_LEAF / Q_SHADE / Q_GEN
 };
 
+typedef __attribute__((address_space(3))) int lds_int;
+
+// The LDS part is addressed through an address_space(3) pointer so that push/pop compile to
+// ds_write_b32/ds_read_b32 (a generic pointer makes the compiler merge the LDS and the HBM
+// overflow path into one flat_load).
 struct SlotStack {
-  int* lds;               // &stack[slot][0]
+  lds_int* lds;           // &stack[slot][0]
   int* ovf;               // this slot's overflow area in HBM (or nullptr)
   __device__ __forceinline__ void store(int sp, int v) {
-    if (sp < kStackN) lds[sp] = v; else ovf[sp - kStackN] = v;
+    if (__builtin_expect(sp < kStackN, 1)) lds[sp] = v; else ovf[sp - kStackN] = v;
   }
-  __device__ __forceinline__ int load(int sp) const { return sp < kStackN ? lds[sp] : ovf[sp - kStackN]; }
+  __device__ __forceinline__ int load(int sp) const {
+    int v;
+    if (__builtin_expect(sp < kStackN, 1)) v = lds[sp]; else v = ovf[sp - kStackN];
+    return v;
+  }
 };
 
 __device__ __forceinline__ int lane_rank(unsigned long long mask) {
@@ -149,7 +158,7 @@ __global__ void __launch_bounds__(kBlockThreads) pt_queuekernel(const LaunchArgs
   };
   auto make_stack = [&](int slot) {
     SlotStack st;
-    st.lds = &W.stack[slot][0];
+    st.lds = (lds_int*)&W.stack[slot][0];
     st.ovf = ovfBase ? ovfBase + (size_t)slot * a.ovfDepth : nullptr;
     return st;
   };

@@ -1,0 +1,31 @@
+import os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from common import M   # noqa: E402
+ctx = M.Context(0)
+W, H = 1920, 1080
+hs = M.HostScene("file:coffee", W, H)
+spp = int(os.environ.get("SPP", "64"))
+seeds = M.launch_seeds(spp)
+def setup(leaf):
+    global rays, B
+    ctx.set_option("leaf_size", leaf); ctx.load(hs)
+    ctx.accum_clear(); st = ctx.render_counted(seeds)
+    rays = st.rays
+    B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+    print("leaf", leaf, "bytes/ray %.1f nodes/ray %.2f tris/ray %.2f" % (B / rays, st.nodeFetches / rays, st.triTests / rays), flush=True)
+def run(tag):
+    best = 1e9
+    for rep in range(2):
+        ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); ms, n = ctx.kernel_time(); best = min(best, ms)
+    print("%-44s %.2f ms  %.1f Mrays/s  %.2f TB/s(alg)" % (tag, best, rays / best / 1e3, B / best / 1e9), flush=True)
+ctx.set_option("kernel_variant", 3)
+setup(4)
+for swap in (16, 24, 32, 40):
+    for starve in (8, 16, 24):
+        ctx.set_option("swap_lanes", swap); ctx.set_option("starve_lanes", starve)
+        run("leaf4 swap%d starve%d" % (swap, starve))
+ctx.set_option("swap_lanes", 24); ctx.set_option("starve_lanes", 16)
+for leaf in (2, 3, 6, 8):
+    setup(leaf); run("leaf%d swap24 starve16" % leaf)

@@ -1,0 +1,23 @@
+"""Quick A/B: coffee full HD at SPP (default 64), default options; prints time + hash."""
+import os, sys, hashlib
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from common import M   # noqa: E402
+ctx = M.Context(0)
+W, H = 1920, 1080
+hs = M.HostScene("file:coffee", W, H)
+spp = int(os.environ.get("SPP", "64"))
+seeds = M.launch_seeds(spp)
+for o in os.environ.get("OPTS", "").split(","):
+    if "=" in o:
+        k, v = o.split("="); ctx.set_option(k, int(v))
+ctx.load(hs)
+ctx.accum_clear(); st = ctx.render_counted(seeds)
+rays = st.rays
+B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+best = 1e9
+for rep in range(3):
+    ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); ms, n = ctx.kernel_time(); best = min(best, ms)
+img = ctx.accum_read()
+print("spp %d: %.2f ms  %.1f Mrays/s  %.2f TB/s(alg)  hash %s" % (spp, best, rays / best / 1e3, B / best / 1e9, hashlib.md5(img.tobytes()).hexdigest()[:10]), flush=True)
