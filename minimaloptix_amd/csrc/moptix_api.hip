@@ -66,7 +66,7 @@ struct moptix_context_t {
   DevBuf<uint8_t> dPoolCold; DevBuf<float> dSampleBuf;
 
   int rank = 0, nRanks = 1;
-  int optExitThreshold = 16, optLeafSize = 4, optBlocksPerCU = 2, optVariant = 3;
+  int optExitThreshold = 16, optLeafSize = 4, optBlocksPerCU = 3, optVariant = 3;
   int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 8192, optLeafThreshold = 16, optSwapLanes = 24;
   unsigned long long lastExtra[5] = { 0, 0, 0, 0, 0 };
 

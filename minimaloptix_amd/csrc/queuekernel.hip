@@ -34,31 +34,35 @@ namespace {
 constexpr int kBlockThreads = 256;
 constexpr int kWaves = kBlockThreads / 64;
 constexpr int kP = 128;                 // slots per wave
-constexpr int kStackN = 12;             // LDS stack entries per slot; deeper levels spill to HBM
+constexpr int kStackN = 11;             // LDS stack entries per slot; deeper levels spill to HBM
+constexpr int kWavesPerSimd = 3;        // occupancy target: 3 workgroups per CU (VGPR <= 168, LDS <= 53 KB)
 
 enum { Q_NODE = 0, Q_LEAF = 1, Q_SHADE = 2, Q_GEN = 3, kNumQ = 4, DEST_DONE = 4, DEST_NONE = -1 };
 
-struct alignas(16) SlotCold {           // 6 x 16 B, HBM, private to the pool
+struct alignas(16) SlotCold {           // 9 x 16 B, HBM, private to the pool
+  // path payload (shading / regeneration batches only)
   int mode, pixel, item, depth;
   uint32_t seed; float thrx, thry, thrz;
   float radx, rady, radz; int mat;
   float Nx, Ny, Nz; int light;
   float Vx, Vy, Vz; float pendInv;
   float pwx, pwy, pwz; int pad0;
+  // "warm" ray state: needed by leaf passes and shading, not by the node loop
+  float dx, dy, dz, tmax;
+  int kind, bestTri, bestPrim, pad1;
+  float c0, c1, c2; int pad2;          // beta, gamma | shadow attenuation
 };
-static_assert(sizeof(SlotCold) == 96, "SlotCold layout");
+static_assert(sizeof(SlotCold) == 144, "SlotCold layout");
 
 struct alignas(16) i4 { int x, y, z, w; };
 
 // LDS image of NS slots
 template <int NS>
 struct PoolLds {
-  v4 rayA[NS];            // o.xyz, tmax
-  v4 rayB[NS];            // d.xyz, kind
-  v4 trvA[NS];            // 1/d, tbest
-  i4 trvB[NS];            // node, sp, bestTri, bestPrim
-  v4 trvC[NS];            // beta|att.x, gamma|att.y, att.z, -
-  int stack[NS][kStackN];
+  // only what the node loop touches lives in LDS: 32 B + the stack per slot
+  v4 nodeA[NS];           // o.xyz, tbest
+  v4 nodeB[NS];           // 1/d, node (int bits)
+  int stack[NS][kStackN + 1];   // [0] = sp | kShadeFlag, [1..] = entries
   unsigned short queue[kNumQ][NS];
   int qHead[kNumQ], qCount[kNumQ];   // SHARED only
   int done, lock;                    // SHARED only
@@ -75,8 +79,10 @@ typedef __attribute__((address_space(3))) int lds_int;
 // The LDS part is addressed through an address_space(3) pointer so that push/pop compile to
 // ds_write_b32/ds_read_b32 (a generic pointer makes the compiler merge the LDS and the HBM
 // overflow path into one flat_load).
+constexpr int kShadeFlag = 1 << 30;   // in stack[slot][0]: a finished ray goes to Q_SHADE (hit or shadow ray), not Q_GEN
+
 struct SlotStack {
-  lds_int* lds;           // &stack[slot][0]
+  lds_int* lds;           // &stack[slot][1]
   int* ovf;               // this slot's overflow area in HBM (or nullptr)
   __device__ __forceinline__ void store(int sp, int v) {
     if (__builtin_expect(sp < kStackN, 1)) lds[sp] = v; else ovf[sp - kStackN] = v;
@@ -104,7 +110,7 @@ __device__ __forceinline__ int route(int node, int kind, int bestPrim) {
 }
 
 template <bool CNT, bool SHARED>
-__global__ void __launch_bounds__(kBlockThreads) pt_queuekernel(const LaunchArgs a) {
+__global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(const LaunchArgs a) {
   constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
   __shared__ PoolLds<NS> sPool[SHARED ? 1 : kWaves];
   __shared__ WavePriv<NS> sPriv[kWaves];
@@ -158,7 +164,7 @@ __global__ void __launch_bounds__(kBlockThreads) pt_queuekernel(const LaunchArgs
   };
   auto make_stack = [&](int slot) {
     SlotStack st;
-    st.lds = (lds_int*)&W.stack[slot][0];
+    st.lds = (lds_int*)&W.stack[slot][1];
     st.ovf = ovfBase ? ovfBase + (size_t)slot * a.ovfDepth : nullptr;
     return st;
   };
@@ -194,6 +200,7 @@ __global__ void __launch_bounds__(kBlockThreads) pt_queuekernel(const LaunchArgs
 
   // ---- node-loop worker context: the only per-lane state that survives between passes ----
   int ns = -1;                 // slot this lane is walking, -1 = none
+  int nsFlag = 0;              // kShadeFlag of that slot
   PathState nray;              // o, tmin used
   nray.o = mk3(0, 0, 0); nray.tmin = sc.epsT; nray.d = mk3(0, 0, 1); nray.tmax = 0; nray.kind = RK_RADIANCE; nray.mode = M_TRACE;
   Trav ntv;                    // inv, tbest, node, sp used
@@ -208,26 +215,34 @@ __global__ void __launch_bounds__(kBlockThreads) pt_queuekernel(const LaunchArgs
     const bool have = slot >= 0;
     if (CNT) { leafPasses++; leafLanes += (uint32_t)__popcll(__ballot(have)); }
     pendSlot = slot; pendDest = DEST_NONE;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (have) {
       PathState ps; Trav tv;
       ps.tmin = sc.epsT; ps.mode = M_TRACE;
-      const v4 ra = W.rayA[slot], rb = W.rayB[slot], ta = W.trvA[slot], tc = W.trvC[slot];
-      const i4 tb = W.trvB[slot];
-      ps.o = mk3(ra.x, ra.y, ra.z); ps.tmax = ra.w; ps.d = mk3(rb.x, rb.y, rb.z); ps.kind = f2i(rb.w);
-      tv.inv = mk3(ta.x, ta.y, ta.z); tv.tbest = ta.w;
-      tv.node = tb.x; tv.sp = tb.y; tv.bestTri = tb.z; tv.bestPrim = tb.w;
-      tv.beta = tc.x; tv.gamma = tc.y; tv.att = mk3(tc.x, tc.y, tc.z);
+      const v4 na = W.nodeA[slot], nb = W.nodeB[slot];
+      const SlotCold* cs = cold + slot;
+      const v4 w0 = *reinterpret_cast<const v4*>(&cs->dx);
+      const i4 w1 = *reinterpret_cast<const i4*>(&cs->kind);
+      const v4 w2 = *reinterpret_cast<const v4*>(&cs->c0);
+      ps.o = mk3(na.x, na.y, na.z); ps.tmax = w0.w; ps.d = mk3(w0.x, w0.y, w0.z); ps.kind = w1.x;
+      tv.inv = mk3(nb.x, nb.y, nb.z); tv.tbest = na.w;
+      tv.node = f2i(nb.w); tv.sp = W.stack[slot][0] & ~kShadeFlag; tv.bestTri = w1.y; tv.bestPrim = w1.z;
+      tv.beta = w2.x; tv.gamma = w2.y; tv.att = mk3(w2.x, w2.y, w2.z);
       SlotStack st = make_stack(slot);
       trav_leaf_step<CNT>(sc, ps, tv, st, ct);
-      W.trvA[slot].w = tv.tbest;
-      i4 nb; nb.x = tv.node; nb.y = tv.sp; nb.z = tv.bestTri; nb.w = tv.bestPrim;
-      W.trvB[slot] = nb;
-      v4 nc;
-      if (ps.kind == RK_SHADOW) { nc.x = tv.att.x; nc.y = tv.att.y; nc.z = tv.att.z; } else { nc.x = tv.beta; nc.y = tv.gamma; nc.z = 0.f; }
-      nc.w = 0.f;
-      W.trvC[slot] = nc;
+      W.nodeA[slot].w = tv.tbest;
+      W.nodeB[slot].w = i2f(tv.node);
+      W.stack[slot][0] = tv.sp | ((ps.kind == RK_SHADOW || tv.bestPrim >= 0) ? kShadeFlag : 0);
+      i4 o1; o1.x = ps.kind; o1.y = tv.bestTri; o1.z = tv.bestPrim; o1.w = 0;
+      v4 o2;
+      if (ps.kind == RK_SHADOW) { o2.x = tv.att.x; o2.y = tv.att.y; o2.z = tv.att.z; } else { o2.x = tv.beta; o2.y = tv.gamma; o2.z = 0.f; }
+      o2.w = 0.f;
+      SlotCold* cw = cold + slot;
+      *reinterpret_cast<i4*>(&cw->kind) = o1;
+      *reinterpret_cast<v4*>(&cw->c0) = o2;
       pendDest = route(tv.node, ps.kind, tv.bestPrim);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // slot records in HBM are re-read by other lanes / waves
   };
 
   // ---- shading / regeneration batch: run the path state machine for the popped slots ----
@@ -238,17 +253,17 @@ __global__ void __launch_bounds__(kBlockThreads) pt_queuekernel(const LaunchArgs
     PathState ps; Trav res;
     ps.mode = M_DONE; ps.kind = RK_RADIANCE;
     res.node = kTravDone; res.bestPrim = -1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (have) {
       const SlotCold c = cold[slot];
-      const v4 ra = W.rayA[slot], rb = W.rayB[slot], ta = W.trvA[slot], tc = W.trvC[slot];
-      const i4 tb = W.trvB[slot];
+      const v4 na = W.nodeA[slot];
       ps.mode = c.mode; ps.pixel = c.pixel; ps.item = c.item; ps.depth = c.depth; ps.seed = c.seed;
       ps.thr = mk3(c.thrx, c.thry, c.thrz); ps.rad = mk3(c.radx, c.rady, c.radz); ps.mat = c.mat;
       ps.N = mk3(c.Nx, c.Ny, c.Nz); ps.light = c.light; ps.V = mk3(c.Vx, c.Vy, c.Vz); ps.pendInv = c.pendInv;
       ps.pendW = mk3(c.pwx, c.pwy, c.pwz); ps.accum = mk3(0, 0, 0);
-      ps.o = mk3(ra.x, ra.y, ra.z); ps.tmax = ra.w; ps.d = mk3(rb.x, rb.y, rb.z); ps.kind = f2i(rb.w); ps.tmin = sc.epsT;
-      res.tbest = ta.w; res.bestTri = tb.z; res.bestPrim = tb.w;
-      res.beta = tc.x; res.gamma = tc.y; res.att = mk3(tc.x, tc.y, tc.z);
+      ps.o = mk3(na.x, na.y, na.z); ps.tmax = c.tmax; ps.d = mk3(c.dx, c.dy, c.dz); ps.kind = c.kind; ps.tmin = sc.epsT;
+      res.tbest = na.w; res.bestTri = c.bestTri; res.bestPrim = c.bestPrim;
+      res.beta = c.c0; res.gamma = c.c1; res.att = mk3(c.c0, c.c1, c.c2);
       if (ps.mode == M_TRACE) ps.mode = M_RESULT;
     }
     for (;;) {
@@ -274,26 +289,27 @@ __global__ void __launch_bounds__(kBlockThreads) pt_queuekernel(const LaunchArgs
       c.thrx = ps.thr.x; c.thry = ps.thr.y; c.thrz = ps.thr.z; c.radx = ps.rad.x; c.rady = ps.rad.y; c.radz = ps.rad.z; c.mat = ps.mat;
       c.Nx = ps.N.x; c.Ny = ps.N.y; c.Nz = ps.N.z; c.light = ps.light; c.Vx = ps.V.x; c.Vy = ps.V.y; c.Vz = ps.V.z; c.pendInv = ps.pendInv;
       c.pwx = ps.pendW.x; c.pwy = ps.pendW.y; c.pwz = ps.pendW.z; c.pad0 = 0;
-      cold[slot] = c;
+      c.dx = ps.d.x; c.dy = ps.d.y; c.dz = ps.d.z; c.tmax = ps.tmax;
+      c.kind = ps.kind; c.bestTri = -1; c.bestPrim = -1; c.pad1 = 0; c.c0 = 0.f; c.c1 = 0.f; c.c2 = 0.f; c.pad2 = 0;
       if (ps.mode == M_TRACE) {
         // new ray: analytic primitives + traversal set-up happen here, on the full batch
         Trav tv;
         trav_begin<CNT>(sc, ps, tv, ct);
-        v4 ra, rb, ta, tc;
-        ra.x = ps.o.x; ra.y = ps.o.y; ra.z = ps.o.z; ra.w = ps.tmax;
-        rb.x = ps.d.x; rb.y = ps.d.y; rb.z = ps.d.z; rb.w = i2f(ps.kind);
-        ta.x = tv.inv.x; ta.y = tv.inv.y; ta.z = tv.inv.z; ta.w = tv.tbest;
-        i4 tb; tb.x = tv.node; tb.y = 0; tb.z = tv.bestTri; tb.w = tv.bestPrim;
-        if (ps.kind == RK_SHADOW) { tc.x = tv.att.x; tc.y = tv.att.y; tc.z = tv.att.z; } else { tc.x = 0.f; tc.y = 0.f; tc.z = 0.f; }
-        tc.w = 0.f;
-        W.rayA[slot] = ra; W.rayB[slot] = rb; W.trvA[slot] = ta; W.trvB[slot] = tb; W.trvC[slot] = tc;
+        v4 na, nb;
+        na.x = ps.o.x; na.y = ps.o.y; na.z = ps.o.z; na.w = tv.tbest;
+        nb.x = tv.inv.x; nb.y = tv.inv.y; nb.z = tv.inv.z; nb.w = i2f(tv.node);
+        W.nodeA[slot] = na; W.nodeB[slot] = nb;
+        W.stack[slot][0] = (ps.kind == RK_SHADOW || tv.bestPrim >= 0) ? kShadeFlag : 0;
+        c.bestTri = tv.bestTri; c.bestPrim = tv.bestPrim;
+        if (ps.kind == RK_SHADOW) { c.c0 = tv.att.x; c.c1 = tv.att.y; c.c2 = tv.att.z; }
+        cold[slot] = c;
         pendDest = route(tv.node, ps.kind, tv.bestPrim);
-      } else if (ps.mode == M_NEW_PIXEL) {
-        pendDest = Q_GEN;
       } else {
-        pendDest = DEST_DONE;
+        cold[slot] = c;
+        pendDest = (ps.mode == M_NEW_PIXEL) ? Q_GEN : DEST_DONE;
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   };
 
   // per-wave private structures: the node-ready ring (slots produced by this wave's own passes
@@ -331,8 +347,8 @@ __global__ void __launch_bounds__(kBlockThreads) pt_queuekernel(const LaunchArgs
       if (__ballot(leave) != 0ull) {
         int dest = DEST_NONE;
         if (leave) {
-          W.trvB[ns].x = ntv.node; W.trvB[ns].y = ntv.sp;
-          dest = route(ntv.node, ntv.node == kTravDone ? f2i(W.rayB[ns].w) : RK_RADIANCE, ntv.node == kTravDone ? W.trvB[ns].w : -1);
+          W.nodeB[ns].w = i2f(ntv.node); W.stack[ns][0] = ntv.sp | nsFlag;
+          dest = (ntv.node == kTravDone) ? (nsFlag ? Q_SHADE : Q_GEN) : Q_LEAF;   // a lane leaves at a leaf or finished
         }
         local_push(dest, ns);
         if (leave) ns = -1;
@@ -344,10 +360,11 @@ __global__ void __launch_bounds__(kBlockThreads) pt_queuekernel(const LaunchArgs
           const int r = lane_rank(m);
           if (r < n) {
             ns = myNodeQ[(nqHead + r) & (NS - 1)];
-            const v4 ra = W.rayA[ns], ta = W.trvA[ns];
-            nray.o = mk3(ra.x, ra.y, ra.z);
-            ntv.inv = mk3(ta.x, ta.y, ta.z); ntv.tbest = ta.w;
-            ntv.node = W.trvB[ns].x; ntv.sp = W.trvB[ns].y;
+            const v4 na = W.nodeA[ns], nb = W.nodeB[ns];
+            const int spw = W.stack[ns][0];
+            nray.o = mk3(na.x, na.y, na.z); ntv.tbest = na.w;
+            ntv.inv = mk3(nb.x, nb.y, nb.z); ntv.node = f2i(nb.w);
+            ntv.sp = spw & ~kShadeFlag; nsFlag = spw & kShadeFlag;
           }
         }
         nqHead = (nqHead + n) & (NS - 1); nqCount -= n;

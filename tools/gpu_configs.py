@@ -1,0 +1,31 @@
+"""BASELINE.json configs other than the headline: parity vs oracle at reduced size + timing at full size."""
+import os, sys, time
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from common import M, O, oracle_scene, rmse   # noqa: E402
+ctx = M.Context(0)
+def parity(kind, kw, res, spp):
+    hs = M.HostScene(kind, res[0], res[1], **kw); seeds = M.launch_seeds(spp)
+    ctx.load(hs); ctx.accum_clear(); st = ctx.render_counted(seeds); g = ctx.accum_read()
+    t0 = time.time(); o, ost = oracle_scene(hs).render(seeds); dt = time.time() - t0
+    print("PARITY %-16s %dx%d spp %d: rmse %.3g rays %d/%d oracle %.1fs tris %d" % (kind, res[0], res[1], spp, rmse(g / spp, o / spp), st.rays, ost.rays, dt, hs.sizes.nFaces), flush=True)
+def timing(kind, kw, res, spp):
+    hs = M.HostScene(kind, res[0], res[1], **kw); seeds = M.launch_seeds(spp)
+    ctx.load(hs); a = ctx.accel_info()
+    ctx.accum_clear(); st = ctx.render_counted(seeds)
+    B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * res[0] * res[1]
+    ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); ms, n = ctx.kernel_time()
+    print("TIMING %-16s %dx%d spp %d: %.1f ms (%d launches) %.1f Mrays/s rays/sample %.2f  alg %.2f TB/s  analytic tests/s %.3g | tris %d nodes %d depth %d build %.2f ms" % (
+        kind, res[0], res[1], spp, ms, n, st.rays / ms / 1e3, st.rays / st.samples, B / ms / 1e9, st.analyticTests / ms * 1e3, a.nTriangles, a.nNodes, a.treeDepth, a.buildMs), flush=True)
+    return ctx.resolve_rgb8(spp)
+parity("cornell_quads", {}, (256, 256), 4)
+parity("random_spheres", dict(iarg=497), (160, 90), 2)
+parity("dining_standin", dict(iarg=3), (96, 54), 1)
+parity("million_standin", dict(iarg=200000), (96, 54), 1)
+from PIL import Image
+for name, kind, kw, res, spp in [("c1", "cornell_quads", {}, (256, 256), 64), ("c2", "random_spheres", dict(iarg=497), (1280, 720), 64),
+                                 ("c2b", "random_spheres", dict(iarg=256), (1280, 720), 64),
+                                 ("c4", "dining_standin", dict(iarg=6), (1920, 1080), 16), ("c5", "million_standin", dict(iarg=1000000), (1920, 1080), 16)]:
+    img = timing(kind, kw, res, spp)
+    Image.fromarray(img).resize((480, 270 if res[0] != res[1] else 480)).save(os.path.join(REPO, "gpurun_out", "cfg_%s.png" % name))
