@@ -50,6 +50,11 @@ void mohost_set_quad_params(const float anchor[3], const float v1[3], const floa
 void mohost_set_cam_params(const float lookFrom[3], const float lookAt[3], const float up[3],
                            float vFoV, float aspect, float aperture, float focus, moptix_cam_params* out);
 
+/* animation of the spheres scene (MinimalOptiX::move/animate, MinimalOptiX.cpp:562-592): advances the n spheres
+ * by `time` and *angle by time*5; mohost_video_camera is the orbit camera of updateVideo (:766-767) */
+void mohost_animate_spheres(moptix_sphere_params* spheres, int32_t n, float time, float* angle);
+void mohost_video_camera(float angle, float aspect, moptix_cam_params* out);
+
 /* .obj ingest on its own (for loader tests): returns face count or <0 */
 int mohost_obj_stats(const char* path, int32_t* nVerts, int32_t* nNormals, int32_t* nTexcoords, int32_t* nShapes);
 

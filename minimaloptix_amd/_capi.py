@@ -113,6 +113,7 @@ HOST_SYMBOLS = [
     "mohost_last_error", "mohost_scene_build", "mohost_scene_free", "mohost_scene_get_sizes",
     "mohost_scene_get_params", "mohost_scene_warning", "mohost_scene_copy", "mohost_scene_upload",
     "mohost_set_quad_params", "mohost_set_cam_params", "mohost_obj_stats", "mohost_render_scene",
+    "mohost_animate_spheres", "mohost_video_camera",
 ]
 
 _dev = None
@@ -189,6 +190,10 @@ def host_lib():
         L.mohost_set_cam_params.argtypes = [C.c_float * 3, C.c_float * 3, C.c_float * 3, C.c_float, C.c_float, C.c_float,
                                             C.c_float, C.POINTER(CamParams)]
         L.mohost_set_cam_params.restype = None
+        L.mohost_animate_spheres.argtypes = [C.POINTER(SphereParams), i32, C.c_float, C.POINTER(C.c_float)]
+        L.mohost_animate_spheres.restype = None
+        L.mohost_video_camera.argtypes = [C.c_float, C.c_float, C.POINTER(CamParams)]
+        L.mohost_video_camera.restype = None
         L.mohost_obj_stats.argtypes = [C.c_char_p, i32p, i32p, i32p, i32p]
         L.mohost_render_scene.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint8), C.POINTER(RenderResult)]

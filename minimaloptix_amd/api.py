@@ -187,6 +187,10 @@ class Context:
     def set_partition(self, rank, nranks):
         self._chk(self._L.moptix_set_partition(self._h, rank, nranks))
 
+    def update_spheres(self, first, spheres, n):
+        """spheres: ctypes array of SphereParams (updateVideo, MinimalOptiX.cpp:763-764)."""
+        self._chk(self._L.moptix_update_spheres(self._h, int(first), spheres, int(n)))
+
     def build_accel(self, kind):
         self._chk(self._L.moptix_build_accel(self._h, kind.encode()))
 

@@ -107,6 +107,19 @@ void mohost_set_cam_params(const float f[3], const float a[3], const float u[3],
   setCamParams(pt::mk3(f[0], f[1], f[2]), pt::mk3(a[0], a[1], a[2]), pt::mk3(u[0], u[1], u[2]), vFoV, aspect, aperture, focus, *out);
 }
 
+void mohost_animate_spheres(moptix_sphere_params* spheres, int32_t n, float time, float* angle) {
+  VideoParams vp;
+  vp.angle = angle ? *angle : 0.f;
+  vp.spheresParams.assign(spheres, spheres + n);
+  animateSpheres(vp, time);
+  for (int32_t i = 0; i < n; i++) spheres[i] = vp.spheresParams[i];
+  if (angle) *angle = vp.angle;
+}
+void mohost_video_camera(float angle, float aspect, moptix_cam_params* out) {
+  VideoParams vp; vp.angle = angle;
+  videoCamera(vp, aspect, *out);
+}
+
 int mohost_obj_stats(const char* path, int32_t* nVerts, int32_t* nNormals, int32_t* nTexcoords, int32_t* nShapes) {
   mobj::attrib_t attrib; std::vector<mobj::shape_t> shapes; std::vector<mobj::material_t> mats; std::string warn, err;
   if (!mobj::LoadObj(&attrib, &shapes, &mats, &warn, &err, path)) { g_err = err; return -1; }

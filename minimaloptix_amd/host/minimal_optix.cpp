@@ -51,7 +51,10 @@ void MinimalOptiX::setupScene() {
     case SCENE_CORNELL: setupScene("cornell"); return;
     case SCENE_HYPERION: setupScene("hyperion"); return;
     case SCENE_DRAGON: setupScene("dragon"); return;
-    case SCENE_SPHERES_VIDEO: buildRandomSpheresScene(scene, 256, fixedWidth, fixedHeight); break;   // :355
+    case SCENE_SPHERES_VIDEO:                                                                          // :355
+      buildRandomSpheresScene(scene, 256, fixedWidth, fixedHeight);
+      videoParams.spheresParams = scene.spheres; videoParams.angle = 0.f;
+      break;
     case SCENE_CORNELL_QUADS: buildCornellQuadsScene(scene, fixedWidth, fixedHeight); break;
     case SCENE_RANDOM_SPHERES_500: buildRandomSpheresScene(scene, 497, fixedWidth, fixedHeight); break;
     case SCENE_DINING_STANDIN: buildDiningStandInScene(scene, baseSceneFolder, 6, fixedWidth, fixedHeight); break;
@@ -112,6 +115,38 @@ void MinimalOptiX::saveCurrentFrame(bool popUpDialog, std::string fileNamePrefix
   std::string fileName = outputDir + "/" + (fileNamePrefix.empty() ? std::string("frame") : fileNamePrefix) + ".png";
   if (!writePNG(fileName, canvas.data(), fixedWidth, fixedHeight)) throw std::runtime_error("cannot write " + fileName);
   if (verbose) fprintf(stderr, "Image saved to %s\n", fileName.c_str());
+}
+
+// MinimalOptiX.cpp:587-592
+void MinimalOptiX::animate(float time) { animateSpheres(videoParams, time); }
+
+// MinimalOptiX.cpp:761-778: advance the physics, rewrite every sphere, new orbit camera, re-render
+void MinimalOptiX::updateVideo() {
+  animate(0.002f);
+  check(moptix_update_spheres(context, 0, videoParams.spheresParams.data(), (int32_t)videoParams.spheresParams.size()), "update spheres");
+  videoCamera(videoParams, (float)fixedWidth / (float)fixedHeight, scene.params.cam);
+  check(moptix_set_params(context, &scene.params), "set params");
+  std::vector<int32_t> seeds(nSuperSampling);
+  for (uint i = 0; i < nSuperSampling; ++i) seeds[i] = randSeed();
+  check(moptix_render(context, seeds.data(), (int32_t)nSuperSampling), "render");
+  updateContent((float)nSuperSampling, true);
+}
+
+// MinimalOptiX.cpp:594-605 (generateVideo is dead code in the reference; frames are saved as PNG)
+void MinimalOptiX::record(int frames, const char* filename, bool saveFrames) {
+  (void)filename;
+  for (int i = 0; i < frames; ++i) {
+    updateVideo();
+    if (saveFrames) saveCurrentFrame(false, "video" + std::to_string(i));
+  }
+}
+
+// MinimalOptiX.cpp:112-117
+void MinimalOptiX::videoDemo() {
+  nSuperSampling = 128u;
+  sceneId = SCENE_SPHERES_VIDEO;
+  renderScene(false, "VIDEO");
+  record(1000, "test.mp4", true);
 }
 
 // MinimalOptiX.cpp:86-110, restricted to the scenes whose assets exist

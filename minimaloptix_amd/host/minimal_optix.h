@@ -35,6 +35,11 @@ public:
   void updateContent(float nAccumulation, bool clearBuffer);
   void saveCurrentFrame(bool popUpDialog, std::string fileNamePrefix = "");
   void imageDemo();
+  void videoDemo();                                            // MinimalOptiX.cpp:112-117
+  void record(int frames, const char* filename, bool saveFrames = false);   // :594-605 (frames are PNGs; no FFmpeg)
+  void updateVideo();                                          // :761-778 one animated frame
+  void animate(float time);                                    // :587-592
+  moptix::VideoParams videoParams;
 
   // components
   std::vector<uint8_t> canvas;        // QImage::Format_RGB888, row 0 = top

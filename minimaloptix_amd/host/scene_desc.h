@@ -78,6 +78,21 @@ void buildDiningStandInScene(SceneDesc& s, const std::string& baseSceneFolder, i
 // BASELINE config 5 stand-in: ~nTris-triangle procedural displaced torus knot (glass) + floor + sphere light
 void buildProceduralMillionScene(SceneDesc& s, int nTrisTarget, uint32_t width, uint32_t height);
 
+// ---- animation of the spheres scene (MinimalOptiX.cpp:562-592, VideoParams MinimalOptiX.h:19-30) ----
+struct VideoParams {
+  const float gravity = 4000.f;
+  const float attenuationCoef = 0.9f;
+  float angle{ 0.0 };
+  pt::v3 lookAt = pt::mk3(0.f, 0.f, 0.f);
+  pt::v3 up = pt::mk3(0.f, 1.f, 0.f);
+  std::vector<moptix_sphere_params> spheresParams;
+};
+// MinimalOptiX::move / animate: ballistic fall with bounces on the plane y = -0.5
+void moveSphere(const VideoParams& vp, moptix_sphere_params& param, float time);
+void animateSpheres(VideoParams& vp, float time);
+// camera of updateVideo (MinimalOptiX.cpp:766-767): orbit of radius 20, rising with the angle
+void videoCamera(const VideoParams& vp, float aspect, moptix_cam_params& cam);
+
 // Push the description through the C ABI: clear_scene, set_params, add_material..., build_accel.
 // Returns MOPTIX_OK or the failing call's error code.
 int upload(const SceneDesc& s, moptix_context ctx);

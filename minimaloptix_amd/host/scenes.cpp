@@ -339,6 +339,46 @@ void buildCornellQuadsScene(SceneDesc& s, uint32_t width, uint32_t height) {
   setCamParams(lookFrom, lookAt, mk3(0.f, 1.f, 0.f), (float)39.3077, (float)width / (float)height, 0.f, 1.f, s.params.cam);
 }
 
+// ---------------------------------------------------------------- animation ---------------
+// MinimalOptiX.cpp:562-585
+void moveSphere(const VideoParams& vp, moptix_sphere_params& param, float time) {
+  float distance = param.velocity.y * time + time * time * vp.gravity / 2.0f;
+  if (distance < param.center.y - param.radius + 0.5f) {   // -0.5f is the plane
+    param.center.x += param.velocity.x * time;
+    param.center.z += param.velocity.z * time;
+    param.center.y -= distance;
+    param.velocity.y += vp.gravity * time;
+  } else {
+    // Divergence D7: for a sphere that already pokes through the plane (the three r=3 spheres at y=2 do)
+    // the radicand is negative; the reference then recurses forever on NaN.  Clamped to 0 here, which
+    // snaps such a sphere onto the plane at rest.
+    float vend = sqrtf(fmaxf(0.0f, param.velocity.y * param.velocity.y + (2.0f * vp.gravity * (param.center.y - param.radius + 0.5f))));
+    float t = (vend - param.velocity.y) / vp.gravity;
+    if (t < 1e-6) {
+      param.velocity.y = 0.f;
+      param.center.y = -0.5f + param.radius;
+      return;
+    }
+    param.center.x += param.velocity.x * t;
+    param.center.z += param.velocity.z * t;
+    param.center.y = -0.5f + param.radius;
+    param.velocity.x *= vp.attenuationCoef;
+    param.velocity.y *= vp.attenuationCoef;
+    param.velocity.y = -vend * vp.attenuationCoef;
+    moveSphere(vp, param, time - t);
+  }
+}
+// MinimalOptiX.cpp:587-592
+void animateSpheres(VideoParams& vp, float time) {
+  vp.angle += time * 5;
+  for (size_t i = 0; i < vp.spheresParams.size(); ++i) moveSphere(vp, vp.spheresParams[i], time);
+}
+// MinimalOptiX.cpp:766-767
+void videoCamera(const VideoParams& vp, float aspect, moptix_cam_params& cam) {
+  const v3 lookFrom = mk3(20 * sinf(vp.angle), (float)std::min(12.0, vp.angle / 10 + 8.0), 20.f * cosf(vp.angle));
+  setCamParams(lookFrom, vp.lookAt, vp.up, 45, aspect, .2f, 20.f, cam);
+}
+
 // ---------------------------------------------------------------- upload ------------------
 int upload(const SceneDesc& s, moptix_context ctx) {
   int rc;

@@ -126,6 +126,8 @@ def lib():
         L.orc_trace_one.argtypes = [C.POINTER(OrcScene), f3, f3, C.c_int32, f3]
         L.orc_closest_hit.restype = C.c_int
         L.orc_closest_hit.argtypes = [C.POINTER(OrcScene), f3, f3, C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.orc_move_sphere.restype = None
+        L.orc_move_sphere.argtypes = [f3, C.c_float, f3, C.c_float]
         L.orc_num_threads.restype = C.c_int
         _lib = L
     return _lib

@@ -786,6 +786,24 @@ static f3 camera_sample(Ctx* cx, int32_t x, int32_t y, int32_t launchSeed) {
   return mk3(clampf(pld.color.x, 0.f, 1.f), clampf(pld.color.y, 0.f, 1.f), clampf(pld.color.z, 0.f, 1.f));
 }
 
+/* MinimalOptiX.cpp:562-585; gravity 4000, attenuation 0.9 (MinimalOptiX.h:23-24) */
+void orc_move_sphere(float c[3], float radius, float v[3], float time) {
+  const float gravity = 4000.f, attenuationCoef = 0.9f;
+  for (;;) {
+    float distance = v[1] * time + time * time * gravity / 2.0f;
+    if (distance < c[1] - radius + 0.5f) {
+      c[0] += v[0] * time; c[2] += v[2] * time; c[1] -= distance; v[1] += gravity * time;
+      return;
+    }
+    float vend = sqrtf(fmaxf(0.0f, v[1] * v[1] + (2.0f * gravity * (c[1] - radius + 0.5f))));   /* D7: NaN guard, see DESIGN.md */
+    float t = (vend - v[1]) / gravity;
+    if (t < 1e-6) { v[1] = 0.f; c[1] = -0.5f + radius; return; }
+    c[0] += v[0] * t; c[2] += v[2] * t; c[1] = -0.5f + radius;
+    v[0] *= attenuationCoef; v[1] *= attenuationCoef; v[1] = -vend * attenuationCoef;
+    time = time - t;
+  }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

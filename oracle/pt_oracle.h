@@ -139,6 +139,8 @@ void  orc_disney_sample(int32_t* seed, const OrcMaterial* m, const float N[3], c
 int   orc_intersect_triangle(const float o[3], const float d[3], float tmin, float tmax,
                              const float p0[3], const float p1[3], const float p2[3],
                              float n[3], float* t, float* beta, float* gamma);
+/* MinimalOptiX::move (MinimalOptiX.cpp:562-585): one sphere {center[3], radius, velocity[3]} for `time` seconds */
+void  orc_move_sphere(float center[3], float radius, float velocity[3], float time);
 int   orc_num_threads(void);
 
 #ifdef __cplusplus

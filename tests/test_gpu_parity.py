@@ -136,3 +136,33 @@ def test_bvh_trace_equals_oracle_closest_hit(gpu_ctx):
             hits += 1
             assert tt == t[i]
     assert hits > 20
+
+
+def test_update_video_frame_matches_oracle(gpu_ctx):
+    """updateVideo (MinimalOptiX.cpp:761-778): animate, rewrite the spheres, new orbit camera, re-render."""
+    import ctypes as C
+    K = M._capi
+    hs = M.HostScene("random_spheres", 160, 90, iarg=60)
+    gpu_ctx.load(hs)
+    n = hs.sizes.nSpheres
+    sph = (K.SphereParams * n)()
+    for i in range(n):
+        sph[i] = hs.flat()["spheres"][i]
+    angle = C.c_float(0.0)
+    for _ in range(25):
+        K.host_lib().mohost_animate_spheres(sph, n, 0.002, C.byref(angle))
+    params = K.Params.from_buffer_copy(hs.params)
+    K.host_lib().mohost_video_camera(angle.value, 160 / 90, C.byref(params.cam))
+    gpu_ctx.update_spheres(0, sph, n)
+    gpu_ctx.set_params(params)
+    seeds = M.launch_seeds(2, first=100)
+    gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+    g = gpu_ctx.accum_read()
+    d = hs.to_dict()
+    d["spheres"] = np.array([[sph[i].center.x, sph[i].center.y, sph[i].center.z, sph[i].radius] for i in range(n)], np.float32)
+    cam = params.cam
+    d["cam"] = {k: getattr(cam, k).tolist() for k in ("origin", "horizontal", "vertical", "scrLowerLeftCorner", "u", "v")}
+    d["cam"]["lensRadius"] = cam.lensRadius
+    o, _ = O.Scene(d).render(seeds)
+    assert rmse(g / 2, o / 2) <= RMSE_TIGHT
+    assert not np.array_equal(d["spheres"], hs.to_dict()["spheres"])       # the scene really moved

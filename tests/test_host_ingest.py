@@ -115,3 +115,37 @@ def test_builtin_scenes():
     assert np.array_equal(r2.to_dict()["spheres"], sp)                                  # deterministic layout (mt19937(42))
     c = M.HostScene("cornell_quads", 256, 256)
     assert (c.sizes.nQuads, c.sizes.nSpheres, c.sizes.nFaces) == (16, 0, 0)
+
+
+def test_animation_matches_oracle_restatement():
+    """MinimalOptiX::move/animate (MinimalOptiX.cpp:562-592): the host's physics step against the
+    oracle's plain-C restatement, bit for bit over 300 frames (free fall, bounces, coming to rest)."""
+    from common import O
+    hs = M.HostScene("random_spheres", 320, 180, iarg=40)
+    f = hs.flat()
+    n = hs.sizes.nSpheres
+    sph = (K.SphereParams * n)()
+    for i in range(n):
+        sph[i] = f["spheres"][i]
+    ref = [([sph[i].center.x, sph[i].center.y, sph[i].center.z], sph[i].radius, [0.0, 0.0, 0.0]) for i in range(n)]
+    angle = C.c_float(0.0)
+    L = O.lib()
+    moved = 0
+    for frame in range(300):
+        K.host_lib().mohost_animate_spheres(sph, n, 0.002, C.byref(angle))
+        for i in range(n):
+            c, r, v = O.f3(*ref[i][0]), ref[i][1], O.f3(*ref[i][2])
+            L.orc_move_sphere(c, r, v, 0.002)
+            ref[i] = (list(c), r, list(v))
+            assert [sph[i].center.x, sph[i].center.y, sph[i].center.z] == list(c), (frame, i)
+            assert [sph[i].velocity.x, sph[i].velocity.y, sph[i].velocity.z] == list(v), (frame, i)
+        moved += 1
+    assert abs(angle.value - 300 * 0.002 * 5) < 1e-4
+    # everything has fallen onto the plane y = -0.5 or is still bouncing above it
+    assert all(sph[i].center.y >= -0.5 + sph[i].radius - 1e-4 for i in range(n))
+    # the three r=3 spheres start below the plane: divergence D7 snaps them onto it at rest
+    assert all(sph[i].center.y == 2.5 and sph[i].velocity.y == 0.0 for i in range(3))
+    assert any(sph[i].velocity.y < 0 for i in range(3, n))            # somebody is on the way up after a bounce
+    cam = K.CamParams()
+    K.host_lib().mohost_video_camera(angle.value, 16 / 9, C.byref(cam))
+    assert abs(cam.origin.y - min(12.0, angle.value / 10 + 8.0)) < 1e-5 and abs(cam.lensRadius - 0.1) < 1e-7
