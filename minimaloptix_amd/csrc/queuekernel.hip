@@ -238,8 +238,11 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       if (ps.kind == RK_SHADOW) { o2.x = tv.att.x; o2.y = tv.att.y; o2.z = tv.att.z; } else { o2.x = tv.beta; o2.y = tv.gamma; o2.z = 0.f; }
       o2.w = 0.f;
       SlotCold* cw = cold + slot;
-      *reinterpret_cast<i4*>(&cw->kind) = o1;
-      *reinterpret_cast<v4*>(&cw->c0) = o2;
+      // most leaf visits find nothing nearer: only write the hit record back when it changed
+      if (o1.y != w1.y || o1.z != w1.z || o2.x != w2.x || o2.y != w2.y || o2.z != w2.z) {
+        *reinterpret_cast<i4*>(&cw->kind) = o1;
+        *reinterpret_cast<v4*>(&cw->c0) = o2;
+      }
       pendDest = route(tv.node, ps.kind, tv.bestPrim);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // slot records in HBM are re-read by other lanes / waves
