@@ -166,3 +166,64 @@ def test_update_video_frame_matches_oracle(gpu_ctx):
     o, _ = O.Scene(d).render(seeds)
     assert rmse(g / 2, o / 2) <= RMSE_TIGHT
     assert not np.array_equal(d["spheres"], hs.to_dict()["spheres"])       # the scene really moved
+
+
+def _tiny_scene(tmp_path, n_tris):
+    """A file scene with n_tris triangles (n <= leaf size => the BVH root is a leaf) and one quad light."""
+    d = tmp_path / "scenes" / "cornell"
+    d.mkdir(parents=True)
+    lines = []
+    for k in range(n_tris):
+        z = -0.2 * k
+        lines += ["v %g -1 %g" % (-1 + 0.1 * k, z), "v %g -1 %g" % (1 + 0.1 * k, z), "v 0 1 %g" % z]
+    lines += ["vn 0 0 1"]
+    lines += ["f %d//1 %d//1 %d//1" % (3 * k + 1, 3 * k + 2, 3 * k + 3) for k in range(n_tris)]
+    (d / "a.obj").write_text("\n".join(lines) + "\n")
+    (d / "cornell.scene").write_text(
+        "material M\n{\n\tcolor 0.8 0.3 0.2\n\troughness 0.4\n}\n"
+        "mesh\n{\n\tfile a.obj\n\tmaterial M\n}\n"
+        "light\n{\n\ttype Quad\n\tposition -1 1.5 2\n\tv1 1 1.5 2\n\tv2 -1 2.5 2.5\n\temission 5 5 5\n}\n")
+    return str(tmp_path / "scenes") + "/"
+
+
+@pytest.mark.parametrize("n_tris", [1, 3, 5, 9])
+@pytest.mark.parametrize("variant", [0, 3])
+def test_tiny_meshes_root_leaf_and_shallow_trees(gpu_ctx, tmp_path, n_tris, variant):
+    base = _tiny_scene(tmp_path, n_tris)
+    hs = M.HostScene("file:cornell", 96, 64, base_folder=base)
+    seeds = M.launch_seeds(3)
+    default = gpu_ctx.get_option("kernel_variant")
+    try:
+        gpu_ctx.set_option("kernel_variant", variant)
+        gpu_ctx.load(hs); gpu_ctx.accum_clear()
+        st = gpu_ctx.render_counted(seeds)
+        g = gpu_ctx.accum_read()
+    finally:
+        gpu_ctx.set_option("kernel_variant", default)
+    o, ost = oracle_scene(hs).render(seeds)
+    assert rmse(g / 3, o / 3) <= RMSE_TIGHT and st.rays == ost.rays
+    assert g.max() > 0.05
+
+
+def test_odd_frame_sizes_and_partitions(gpu_ctx):
+    """Frames that are not multiples of the 8x8 tile, rendered whole and as 3 tile-split partitions."""
+    hs = M.HostScene("file:coffee", 101, 37)
+    seeds = M.launch_seeds(2)
+    gpu_ctx.load(hs); gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+    whole = gpu_ctx.accum_read()
+    o, _ = oracle_scene(hs).render(seeds)
+    assert rmse(whole / 2, o / 2) <= RMSE_TIGHT
+    from minimaloptix_amd import dist as D
+    parts = np.zeros_like(whole)
+    try:
+        for r in range(3):
+            gpu_ctx.set_partition(r, 3)
+            gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+            a = gpu_ctx.accum_read().reshape(-1, 3)
+            idx = D.tile_pixel_indices(101, 37, r, 3)
+            mask = np.ones(len(a), bool); mask[idx] = False
+            assert not a[mask].any()                       # a rank touches only its own tiles
+            parts.reshape(-1, 3)[idx] = a[idx]
+    finally:
+        gpu_ctx.set_partition(0, 1)
+    assert np.array_equal(parts, whole)                    # tile split is bit-identical to one GPU
