@@ -64,7 +64,7 @@ __global__ void k_morton(int n, const float* __restrict__ lo, const float* __res
   const v3 chi = mk3(ordered_to_float(box->cHi[0]), ordered_to_float(box->cHi[1]), ordered_to_float(box->cHi[2]));
   const v3 invExt = mk3(inv_extent(clo.x, chi.x), inv_extent(clo.y, chi.y), inv_extent(clo.z, chi.z));
   const v3 c = (mk3(lo[3 * f], lo[3 * f + 1], lo[3 * f + 2]) + mk3(hi[3 * f], hi[3 * f + 1], hi[3 * f + 2])) * 0.5f;
-  keys[f] = ((uint64_t)morton30(c, clo, invExt) << 32) | (uint32_t)f;
+  keys[f] = morton_key(c, clo, invExt, lbvh_bits_per_axis(n), lbvh_index_bits(n), f);
 }
 
 // 3. records + padded leaf boxes in sorted order
@@ -74,7 +74,7 @@ __global__ void k_leaves(int n, const uint64_t* __restrict__ keys, const float* 
                          Tri48* __restrict__ tris, TriShade* __restrict__ shade, float* __restrict__ leafLo, float* __restrict__ leafHi) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  const int f = (int)(keys[k] & 0xffffffffu);
+  const int f = key_face(keys[k], lbvh_index_bits(n));
   const float* p = facePos + 9 * (size_t)f;
   const v3 p0 = mk3(p[0], p[1], p[2]), p1 = mk3(p[3], p[4], p[5]), p2 = mk3(p[6], p[7], p[8]);
   Tri48 t;

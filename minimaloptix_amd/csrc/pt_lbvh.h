@@ -2,7 +2,8 @@
 // Acceleration("Trbvh") (MinimalOptiX.cpp:378,494,534; closed source in OptiX).
 //
 //   1. per-triangle bounds + centroid                      (meshBBox, Geometry.cu:162-175)
-//   2. 30-bit Morton code of the centroid in the scene box; key = code<<32 | face  (unique)
+//   2. Morton code of the centroid in the scene box; key = code << idxBits | face  (unique; the code gets
+//      every bit the face index does not need: 15 bits per axis for the coffee scene)
 //   3. radix sort of the keys
 //   4. Karras 2012 radix tree over the sorted keys (one thread per internal node)
 //   5. bottom-up box fit with one atomic arrival counter per node
@@ -18,21 +19,30 @@
 
 namespace pt {
 
-PT_HD uint32_t expand_bits10(uint32_t v) {
-  v = (v * 0x00010001u) & 0xFF0000FFu;
-  v = (v * 0x00000101u) & 0x0F00F00Fu;
-  v = (v * 0x00000011u) & 0xC30C30C3u;
-  v = (v * 0x00000005u) & 0x49249249u;
+// Keys are code << idxBits | face: the face index makes them unique, and all bits it does not need go to
+// the Morton code (3 x bitsPerAxis): 168 k triangles -> 18 index bits -> 15 bits (32768 cells) per axis.
+PT_HD int lbvh_index_bits(int n) { int b = 1; while ((1ll << b) < (long long)n) b++; return b; }
+PT_HD int lbvh_bits_per_axis(int n) { const int b = (64 - lbvh_index_bits(n)) / 3; return b > 21 ? 21 : b; }
+PT_HD uint64_t expand_bits21(uint64_t v) {
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x001f00000000ffffull;
+  v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
   return v;
 }
-// p = centroid, lo/invExt = scene centroid box; 10 bits per axis, x most significant
-PT_HD uint32_t morton30(v3 p, v3 lo, v3 invExt) {
+PT_HD uint64_t morton_key(v3 p, v3 lo, v3 invExt, int bitsPerAxis, int idxBits, int face) {
   const v3 n = (p - lo) * invExt;
-  const float fx = fminf_(fmaxf_(n.x * 1024.0f, 0.0f), 1023.0f);
-  const float fy = fminf_(fmaxf_(n.y * 1024.0f, 0.0f), 1023.0f);
-  const float fz = fminf_(fmaxf_(n.z * 1024.0f, 0.0f), 1023.0f);
-  return (expand_bits10((uint32_t)fx) << 2) | (expand_bits10((uint32_t)fy) << 1) | expand_bits10((uint32_t)fz);
+  const float scale = (float)(1u << bitsPerAxis), top = scale - 1.0f;
+  const uint64_t qx = (uint64_t)fminf_(fmaxf_(n.x * scale, 0.0f), top);
+  const uint64_t qy = (uint64_t)fminf_(fmaxf_(n.y * scale, 0.0f), top);
+  const uint64_t qz = (uint64_t)fminf_(fmaxf_(n.z * scale, 0.0f), top);
+  const uint64_t code = (expand_bits21(qx) << 2) | (expand_bits21(qy) << 1) | expand_bits21(qz);
+  return (code << idxBits) | (uint64_t)(uint32_t)face;
 }
+PT_HD int key_face(uint64_t key, int idxBits) { return (int)(key & ((1ull << idxBits) - 1ull)); }
+
 PT_HD float inv_extent(float lo, float hi) { const float e = hi - lo; return e > 0.0f ? 1.0f / e : 0.0f; }
 
 PT_HD void tri_bounds(v3 p0, v3 p1, v3 p2, v3& lo, v3& hi) {

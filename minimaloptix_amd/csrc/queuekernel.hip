@@ -56,6 +56,35 @@ static_assert(sizeof(SlotCold) == 144, "SlotCold layout");
 
 struct alignas(16) i4 { int x, y, z, w; };
 
+// Slot records stream through the cache hierarchy once per visit; PT_SLOT_NT marks their loads/stores
+// non-temporal so that they do not push BVH nodes out of the 4 MB L2 of the XCD.
+#ifndef PT_SLOT_NT
+#define PT_SLOT_NT 0
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ T slot_load(const T* p) {
+  static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+  if constexpr (PT_SLOT_NT) {
+    T out;
+    const f4v* src = reinterpret_cast<const f4v*>(p); f4v* dst = reinterpret_cast<f4v*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) dst[i] = __builtin_nontemporal_load(src + i);
+    return out;
+  } else {
+    return *p;
+  }
+}
+template <class T> __device__ __forceinline__ void slot_store(T* p, const T& v) {
+  static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+  if constexpr (PT_SLOT_NT) {
+    const f4v* src = reinterpret_cast<const f4v*>(&v); f4v* dst = reinterpret_cast<f4v*>(p);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) __builtin_nontemporal_store(src[i], dst + i);
+  } else {
+    *p = v;
+  }
+}
+
 // LDS image of NS slots
 template <int NS>
 struct PoolLds {
@@ -221,9 +250,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       ps.tmin = sc.epsT; ps.mode = M_TRACE;
       const v4 na = W.nodeA[slot], nb = W.nodeB[slot];
       const SlotCold* cs = cold + slot;
-      const v4 w0 = *reinterpret_cast<const v4*>(&cs->dx);
-      const i4 w1 = *reinterpret_cast<const i4*>(&cs->kind);
-      const v4 w2 = *reinterpret_cast<const v4*>(&cs->c0);
+      const v4 w0 = slot_load(reinterpret_cast<const v4*>(&cs->dx));
+      const i4 w1 = slot_load(reinterpret_cast<const i4*>(&cs->kind));
+      const v4 w2 = slot_load(reinterpret_cast<const v4*>(&cs->c0));
       ps.o = mk3(na.x, na.y, na.z); ps.tmax = w0.w; ps.d = mk3(w0.x, w0.y, w0.z); ps.kind = w1.x;
       tv.inv = mk3(nb.x, nb.y, nb.z); tv.tbest = na.w;
       tv.node = f2i(nb.w); tv.sp = W.stack[slot][0] & ~kShadeFlag; tv.bestTri = w1.y; tv.bestPrim = w1.z;
@@ -240,8 +269,8 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       SlotCold* cw = cold + slot;
       // most leaf visits find nothing nearer: only write the hit record back when it changed
       if (o1.y != w1.y || o1.z != w1.z || o2.x != w2.x || o2.y != w2.y || o2.z != w2.z) {
-        *reinterpret_cast<i4*>(&cw->kind) = o1;
-        *reinterpret_cast<v4*>(&cw->c0) = o2;
+        slot_store(reinterpret_cast<i4*>(&cw->kind), o1);
+        slot_store(reinterpret_cast<v4*>(&cw->c0), o2);
       }
       pendDest = route(tv.node, ps.kind, tv.bestPrim);
     }
@@ -258,7 +287,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     res.node = kTravDone; res.bestPrim = -1;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (have) {
-      const SlotCold c = cold[slot];
+      const SlotCold c = slot_load(cold + slot);
       const v4 na = W.nodeA[slot];
       ps.mode = c.mode; ps.pixel = c.pixel; ps.item = c.item; ps.depth = c.depth; ps.seed = c.seed;
       ps.thr = mk3(c.thrx, c.thry, c.thrz); ps.rad = mk3(c.radx, c.rady, c.radz); ps.mat = c.mat;
@@ -305,10 +334,10 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         W.stack[slot][0] = (ps.kind == RK_SHADOW || tv.bestPrim >= 0) ? kShadeFlag : 0;
         c.bestTri = tv.bestTri; c.bestPrim = tv.bestPrim;
         if (ps.kind == RK_SHADOW) { c.c0 = tv.att.x; c.c1 = tv.att.y; c.c2 = tv.att.z; }
-        cold[slot] = c;
+        slot_store(cold + slot, c);
         pendDest = route(tv.node, ps.kind, tv.bestPrim);
       } else {
-        cold[slot] = c;
+        slot_store(cold + slot, c);
         pendDest = (ps.mode == M_NEW_PIXEL) ? Q_GEN : DEST_DONE;
       }
     }

@@ -7,6 +7,7 @@
 // It is not part of the product: nothing under minimaloptix_amd/ builds or loads it.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../../minimaloptix_amd/csrc/pt_path.h"
@@ -77,13 +78,14 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   const v3 invExt = mk3(inv_extent(clo.x, chi.x), inv_extent(clo.y, chi.y), inv_extent(clo.z, chi.z));
   const float padAbs = 1e-5f * fmaxf_(fmaxf_(shi.x - slo.x, shi.y - slo.y), shi.z - slo.z) + 1e-30f;
   std::vector<uint64_t> keys(n);
-  for (int f = 0; f < n; f++) keys[f] = ((uint64_t)morton30(cen[f], clo, invExt) << 32) | (uint32_t)f;
+  const int idxBits = lbvh_index_bits(n), bitsPerAxis = getenv("HOSTSIM_MORTON30") ? 10 : lbvh_bits_per_axis(n);
+  for (int f = 0; f < n; f++) keys[f] = morton_key(cen[f], clo, invExt, bitsPerAxis, idxBits, f);
   std::sort(keys.begin(), keys.end());
 
   out.tris.resize(n); out.shade.resize(n);
   std::vector<v3> llo(n), lhi(n);
   for (int k = 0; k < n; k++) {
-    const int f = (int)(keys[k] & 0xffffffffu);
+    const int f = key_face(keys[k], idxBits);
     const float* p = s.facePos + 9 * (size_t)f;
     const v3 p0 = mk3(p[0], p[1], p[2]), p1 = mk3(p[3], p[4], p[5]), p2 = mk3(p[6], p[7], p[8]);
     Tri48 t; memset(&t, 0, sizeof(t));
