@@ -56,7 +56,7 @@ enum { MOPTIX_LIGHT_SPHERE = 0, MOPTIX_LIGHT_QUAD = 1 };  /* Structures.h:68 Lig
 
 /* Structures.h:51-66 DisneyParams */
 typedef struct moptix_disney_params {
-  int32_t albedoID;              /* 0 = RT_TEXTURE_ID_NULL; textures: SURVEY 8(f) "next" */
+  int32_t albedoID;              /* 0 = RT_TEXTURE_ID_NULL, else an id from moptix_add_texture */
   moptix_float3 color, emission;
   float metallic, subsurface, specular, roughness, specularTint, anisotropic;
   float sheen, sheenTint, clearcoat, clearcoatGloss;
@@ -129,6 +129,12 @@ int moptix_set_params(moptix_context ctx, const moptix_params* p);
 
 /* ---- scene upload (MinimalOptiX.cpp:168-249, 362-537, 780-843) ------------ */
 int moptix_clear_scene(moptix_context ctx);
+/* createTextureSampler + createBuffer(RT_BUFFER_INPUT, RT_FORMAT_FLOAT4, w, h) + sampler->getId()
+ * (MinimalOptiX.cpp:444-479): RT_WRAP_REPEAT, normalized coordinates, RT_FILTER_LINEAR.  rgba holds
+ * 4*w*h floats, row 0 = texture coordinate v 0 (the caller has already flipped the image as
+ * MinimalOptiX.cpp:464 does).  *outTexId >= 1 goes into DisneyParams.albedoID; add textures before the
+ * materials that name them. */
+int moptix_add_texture(moptix_context ctx, const float* rgba, int32_t width, int32_t height, int32_t* outTexId);
 int moptix_add_material(moptix_context ctx, const moptix_material* m, int32_t* outMatId);
 /* createGeometry+sphereIntersect/sphereBBox+createGeometryInstance (MinimalOptiX.cpp:177-208,796-843) */
 int moptix_add_spheres(moptix_context ctx, const moptix_sphere_params* s, const int32_t* matIds, int32_t n);

@@ -21,6 +21,7 @@ typedef struct mohost_scene_t* mohost_scene;
 
 typedef struct mohost_scene_sizes {
   int32_t nMaterials, nSpheres, nQuads, nLights, nVerts, nNormals, nTexcoords, nFaces, nMeshes, nWarnings;
+  int32_t nTextures;
 } mohost_scene_sizes;
 
 const char* mohost_last_error(void);
@@ -42,7 +43,15 @@ int mohost_scene_copy(mohost_scene s, moptix_material* materials,
                       moptix_sphere_params* spheres, int32_t* sphereMat,
                       moptix_quad_params* quads, int32_t* quadMat, moptix_light_params* lights,
                       float* positions, float* normals, int32_t* vIdx, int32_t* nIdx, int32_t* faceMat);
-/* clear_scene + set_params + add_* + set_lights + build_accel on ctx */
+/* texcoords (2*nTexcoords floats, meshes concatenated) and the rebased per-face indices (3*nFaces, -1 = none) */
+int mohost_scene_copy_texcoords(mohost_scene s, float* texcoords, int32_t* tIdx);
+/* texture i (< nTextures; DisneyParams.albedoID - 1): size and, if rgba != NULL, its 4*w*h floats as uploaded
+ * (MinimalOptiX.cpp:459-472: row 0 = bottom image row, alpha 1) */
+int mohost_scene_texture(mohost_scene s, int32_t i, int32_t* width, int32_t* height, float* rgba);
+/* QImage(path) stand-in used for albedoTex files: PNG (non-interlaced) and binary PNM -> 8-bit RGB, row 0 = top.
+ * rgb may be NULL to query the size. */
+int mohost_read_image(const char* path, int32_t* width, int32_t* height, uint8_t* rgb, uint64_t rgbCapacity);
+/* clear_scene + set_params + add_texture + add_* + set_lights + build_accel on ctx */
 int mohost_scene_upload(mohost_scene s, moptix_context ctx);
 
 /* utils_host.cpp:67-99 */

@@ -91,7 +91,7 @@ class AccelInfo(C.Structure):
 
 class SceneSizes(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nMaterials", "nSpheres", "nQuads", "nLights", "nVerts", "nNormals",
-                                          "nTexcoords", "nFaces", "nMeshes", "nWarnings")]
+                                          "nTexcoords", "nFaces", "nMeshes", "nWarnings", "nTextures")]
 
 
 class RenderResult(C.Structure):
@@ -102,7 +102,7 @@ class RenderResult(C.Structure):
 # every symbol include/moptix.h declares (tests check that the library exports all of them)
 DEVICE_SYMBOLS = [
     "moptix_create", "moptix_destroy", "moptix_last_error", "moptix_version", "moptix_set_stream",
-    "moptix_set_params", "moptix_clear_scene", "moptix_add_material", "moptix_add_spheres", "moptix_add_quads",
+    "moptix_set_params", "moptix_clear_scene", "moptix_add_texture", "moptix_add_material", "moptix_add_spheres", "moptix_add_quads",
     "moptix_add_mesh", "moptix_set_lights", "moptix_update_spheres", "moptix_build_accel", "moptix_get_accel_info",
     "moptix_validate", "moptix_launch", "moptix_render", "moptix_render_async", "moptix_sync",
     "moptix_render_counted", "moptix_set_partition", "moptix_set_option", "moptix_get_option",
@@ -113,7 +113,8 @@ HOST_SYMBOLS = [
     "mohost_last_error", "mohost_scene_build", "mohost_scene_free", "mohost_scene_get_sizes",
     "mohost_scene_get_params", "mohost_scene_warning", "mohost_scene_copy", "mohost_scene_upload",
     "mohost_set_quad_params", "mohost_set_cam_params", "mohost_obj_stats", "mohost_render_scene",
-    "mohost_animate_spheres", "mohost_video_camera",
+    "mohost_animate_spheres", "mohost_video_camera", "mohost_scene_copy_texcoords", "mohost_scene_texture",
+    "mohost_read_image",
 ]
 
 _dev = None
@@ -141,6 +142,7 @@ def device_lib():
         L.moptix_set_params.argtypes = [vp, C.POINTER(Params)]
         L.moptix_clear_scene.argtypes = [vp]
         L.moptix_add_material.argtypes = [vp, C.POINTER(Material), i32p]
+        L.moptix_add_texture.argtypes = [vp, f32p, i32, i32, i32p]
         L.moptix_add_spheres.argtypes = [vp, C.POINTER(SphereParams), i32p, i32]
         L.moptix_add_quads.argtypes = [vp, C.POINTER(QuadParams), i32p, i32]
         L.moptix_add_mesh.argtypes = [vp, f32p, i32, f32p, i32, f32p, i32, i32p, i32p, i32p, i32, i32]
@@ -185,6 +187,9 @@ def host_lib():
         L.mohost_scene_copy.argtypes = [vp, C.POINTER(Material), C.POINTER(SphereParams), i32p, C.POINTER(QuadParams), i32p,
                                         C.POINTER(LightParams), f32p, f32p, i32p, i32p, i32p]
         L.mohost_scene_upload.argtypes = [vp, vp]
+        L.mohost_scene_copy_texcoords.argtypes = [vp, f32p, i32p]
+        L.mohost_scene_texture.argtypes = [vp, i32, i32p, i32p, f32p]
+        L.mohost_read_image.argtypes = [C.c_char_p, i32p, i32p, C.POINTER(C.c_uint8), C.c_uint64]
         L.mohost_set_quad_params.argtypes = [C.c_float * 3, C.c_float * 3, C.c_float * 3, C.POINTER(QuadParams)]
         L.mohost_set_quad_params.restype = None
         L.mohost_set_cam_params.argtypes = [C.c_float * 3, C.c_float * 3, C.c_float * 3, C.c_float, C.c_float, C.c_float,

@@ -90,9 +90,19 @@ class HostScene:
             fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
             K.host_lib().mohost_scene_copy(self._h, mats, sph, ip(smat), quads, ip(qmat), lights, fp(pos), fp(nrm),
                                            ip(vi), ip(ni), ip(fm))
+            uv = np.zeros((max(1, s.nTexcoords), 2), np.float32); ti = np.full((max(1, s.nFaces), 3), -1, np.int32)
+            K.host_lib().mohost_scene_copy_texcoords(self._h, fp(uv), ip(ti))
+            textures = []
+            for t in range(s.nTextures):
+                w, h = C.c_int32(), C.c_int32()
+                K.host_lib().mohost_scene_texture(self._h, t, C.byref(w), C.byref(h), None)
+                px = np.zeros((h.value, w.value, 4), np.float32)
+                K.host_lib().mohost_scene_texture(self._h, t, None, None, fp(px))
+                textures.append(px)
             self._flat = dict(materials=mats, spheres=sph, sphereMat=smat[:s.nSpheres], quads=quads, quadMat=qmat[:s.nQuads],
                               lights=lights, positions=pos[:s.nVerts], normals=nrm[:s.nNormals], vIdx=vi[:s.nFaces],
-                              nIdx=ni[:s.nFaces], faceMat=fm[:s.nFaces])
+                              nIdx=ni[:s.nFaces], faceMat=fm[:s.nFaces], texcoords=uv[:s.nTexcoords], tIdx=ti[:s.nFaces],
+                              textures=textures)
         return self._flat
 
     def to_dict(self):
@@ -121,7 +131,8 @@ class HostScene:
                     bgColor=_f3(p.bgColor), rayMaxDepth=int(p.rayMaxDepth), rayMinIntensity=float(p.rayMinIntensity),
                     rayEpsilonT=float(p.rayEpsilonT), materials=mats, spheres=spheres, sphereMat=f["sphereMat"],
                     quads=quads, quadMat=f["quadMat"], lights=lights, positions=f["positions"], normals=f["normals"],
-                    vIdx=f["vIdx"], nIdx=f["nIdx"], faceMat=f["faceMat"])
+                    vIdx=f["vIdx"], nIdx=f["nIdx"], faceMat=f["faceMat"], texcoords=f["texcoords"], tIdx=f["tIdx"],
+                    textures=f["textures"])
 
     def face_arrays(self):
         """Per-face positions / normals (9 floats each) + flags, as moptix_add_mesh flattens them."""
@@ -135,6 +146,18 @@ class HostScene:
             idx = np.where(has.astype(bool))[0]
             face_nrm[idx] = f["normals"][ni[idx].reshape(-1)].reshape(-1, 9)
         return face_pos, face_nrm, has, f["faceMat"]
+
+    def face_uvs(self):
+        """Per-face texcoords (6 floats: u0 v0 u1 v1 u2 v2) + flags, as moptix_add_mesh flattens them."""
+        f = self.flat()
+        ti = f["tIdx"]
+        nf = len(ti)
+        has = (ti >= 0).all(axis=1).astype(np.int32) if nf else np.zeros(0, np.int32)
+        uv = np.zeros((nf, 6), np.float32)
+        if nf and has.any():
+            idx = np.where(has.astype(bool))[0]
+            uv[idx] = f["texcoords"][ti[idx].reshape(-1)].reshape(-1, 6)
+        return uv, has
 
 
 class Context:

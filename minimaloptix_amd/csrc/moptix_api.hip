@@ -55,11 +55,15 @@ struct moptix_context_t {
   std::vector<DevQuad> quads;
   std::vector<DevLight> lights;
   std::vector<float> facePos, faceNrm; std::vector<int> faceHasNrm, faceMat;
+  std::vector<TriUV> faceUV; bool anyUV = false;
+  struct HostTexture { int width, height; std::vector<float> rgba; };
+  std::vector<HostTexture> textures;
   bool sceneDirty = true, accelBuilt = false;
 
   // device
   DevBuf<DevMaterial> dMats; DevBuf<DevSphere> dSpheres; DevBuf<int> dSphereMat; DevBuf<DevQuad> dQuads; DevBuf<DevLight> dLights;
   DevBuf<float> dFacePos, dFaceNrm; DevBuf<int> dFaceHasNrm, dFaceMat;
+  DevBuf<TriUV> dFaceUV; DevBuf<float> dTexels; DevBuf<DevTexture> dTextures;
   LbvhResult bvh;
   DevBuf<float> dAccum; float* accumBound = nullptr; size_t accumPixels = 0;
   DevBuf<int> dSeeds; DevBuf<int> dWork; DevBuf<unsigned long long> dCounters; DevBuf<int> dOverflow; DevBuf<uint8_t> dRgb8;
@@ -113,6 +117,8 @@ void fill_view(moptix_context c, SceneView& v) {
   for (size_t i = 0; i < c->quads.size(); i++) if (c->mats[c->quads[i].mat].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
   v.nTris = c->bvh.nTris; v.rootRef = c->bvh.nTris > 0 ? c->bvh.rootRef : kEmptyRef;
   v.nodes = c->bvh.nodes; v.tris = c->bvh.tris; v.triShade = c->bvh.shade;
+  v.triUV = (c->anyUV && c->bvh.nTris > 0) ? c->dFaceUV.p : nullptr;
+  v.nTextures = (int)c->textures.size(); v.textures = c->dTextures.p;
 }
 
 int check_ready(moptix_context c) {
@@ -263,6 +269,7 @@ int moptix_destroy(moptix_context c) {
   (void)hipStreamSynchronize(c->stream);
   c->dMats.release(); c->dSpheres.release(); c->dSphereMat.release(); c->dQuads.release(); c->dLights.release();
   c->dFacePos.release(); c->dFaceNrm.release(); c->dFaceHasNrm.release(); c->dFaceMat.release();
+  c->dFaceUV.release(); c->dTexels.release(); c->dTextures.release();
   lbvh_free(&c->bvh);
   c->dPoolCold.release(); c->dSampleBuf.release();
   c->dAccum.release(); c->dSeeds.release(); c->dWork.release(); c->dCounters.release(); c->dOverflow.release(); c->dRgb8.release();
@@ -296,6 +303,18 @@ int moptix_clear_scene(moptix_context c) {
   if (!c) return MOPTIX_ERR_INVALID;
   c->mats.clear(); c->spheres.clear(); c->sphereMat.clear(); c->quads.clear(); c->lights.clear();
   c->facePos.clear(); c->faceNrm.clear(); c->faceHasNrm.clear(); c->faceMat.clear();
+  c->faceUV.clear(); c->anyUV = false; c->textures.clear();
+  c->sceneDirty = true; c->accelBuilt = false;
+  return MOPTIX_OK;
+}
+
+int moptix_add_texture(moptix_context c, const float* rgba, int32_t width, int32_t height, int32_t* outTexId) {
+  if (!c || !rgba || width <= 0 || height <= 0) return fail(c, MOPTIX_ERR_INVALID, "bad texture");
+  moptix_context_t::HostTexture t;
+  t.width = width; t.height = height;
+  t.rgba.assign(rgba, rgba + 4 * (size_t)width * (size_t)height);
+  c->textures.push_back(std::move(t));
+  if (outTexId) *outTexId = (int32_t)c->textures.size();     // ids start at 1; 0 is RT_TEXTURE_ID_NULL
   c->sceneDirty = true; c->accelBuilt = false;
   return MOPTIX_OK;
 }
@@ -303,6 +322,8 @@ int moptix_clear_scene(moptix_context c) {
 int moptix_add_material(moptix_context c, const moptix_material* m, int32_t* outMatId) {
   if (!c || !m) return fail(c, MOPTIX_ERR_INVALID, "null argument");
   if (m->kind < MOPTIX_MAT_LAMBERTIAN || m->kind > MOPTIX_MAT_LIGHT) return fail(c, MOPTIX_ERR_INVALID, "unknown material kind");
+  if (m->kind == MOPTIX_MAT_DISNEY && (m->disney.albedoID < 0 || (size_t)m->disney.albedoID > c->textures.size()))
+    return fail(c, MOPTIX_ERR_INVALID, "albedoID names no texture (add textures before the materials that use them)");
   c->mats.push_back(make_dev_material(*m));
   if (outMatId) *outMatId = (int32_t)c->mats.size() - 1;
   c->sceneDirty = true; c->accelBuilt = false;
@@ -337,12 +358,12 @@ int moptix_add_quads(moptix_context c, const moptix_quad_params* q, const int32_
 int moptix_add_mesh(moptix_context c, const float* positions, int32_t nVerts, const float* normals, int32_t nNormals,
                     const float* texcoords, int32_t nTexcoords, const int32_t* vIdx, const int32_t* nIdx, const int32_t* tIdx,
                     int32_t nFaces, int32_t matId) {
-  (void)texcoords; (void)nTexcoords; (void)tIdx;   // texcoords feed only the texture path
   if (!c || nFaces < 0 || nVerts < 0 || (nFaces > 0 && (!positions || !vIdx))) return fail(c, MOPTIX_ERR_INVALID, "bad argument");
   if (check_mat(c, matId) != MOPTIX_OK) return MOPTIX_ERR_INVALID;
   for (int32_t f = 0; f < 3 * nFaces; f++)
     if (vIdx[f] < 0 || vIdx[f] >= nVerts) return fail(c, MOPTIX_ERR_INVALID, "vertex index out of range");
   const bool meshHasNormals = normals && nNormals > 0 && nIdx;      // normalBuffer.size() != 0, Geometry.cu:136
+  const bool meshHasUVs = texcoords && nTexcoords > 0 && tIdx;      // texcoordBuffer.size() != 0, Geometry.cu:141
   for (int32_t f = 0; f < nFaces; f++) {
     bool hasN = meshHasNormals;
     for (int k = 0; k < 3; k++) {
@@ -356,6 +377,17 @@ int moptix_add_mesh(moptix_context c, const float* positions, int32_t nVerts, co
     }
     c->faceHasNrm.push_back(hasN ? 1 : 0);
     c->faceMat.push_back(matId);
+    TriUV uv; memset(&uv, 0, sizeof(uv));
+    if (meshHasUVs) {
+      const int32_t* ti = tIdx + 3 * (size_t)f;
+      if (ti[0] >= 0 && ti[0] < nTexcoords && ti[1] >= 0 && ti[1] < nTexcoords && ti[2] >= 0 && ti[2] < nTexcoords) {
+        uv.u0 = texcoords[2 * (size_t)ti[0]]; uv.v0 = texcoords[2 * (size_t)ti[0] + 1];
+        uv.u1 = texcoords[2 * (size_t)ti[1]]; uv.v1 = texcoords[2 * (size_t)ti[1] + 1];
+        uv.u2 = texcoords[2 * (size_t)ti[2]]; uv.v2 = texcoords[2 * (size_t)ti[2] + 1];
+        uv.hasUV = 1; c->anyUV = true;
+      }
+    }
+    c->faceUV.push_back(uv);
   }
   c->sceneDirty = true; c->accelBuilt = false;
   return MOPTIX_OK;
@@ -395,8 +427,19 @@ int moptix_build_accel(moptix_context c, const char* kind) {
   HIPCHK(c, c->dSphereMat.upload(c->sphereMat, c->stream), "upload sphere materials");
   HIPCHK(c, c->dQuads.upload(c->quads, c->stream), "upload quads");
   HIPCHK(c, c->dLights.upload(c->lights, c->stream), "upload lights");
+  {  // texture buffers: all texels in one allocation, one descriptor per sampler
+    std::vector<float> texels; std::vector<size_t> offs;
+    for (const auto& t : c->textures) { offs.push_back(texels.size()); texels.insert(texels.end(), t.rgba.begin(), t.rgba.end()); }
+    HIPCHK(c, c->dTexels.upload(texels, c->stream), "upload texels");
+    std::vector<DevTexture> desc;
+    for (size_t i = 0; i < c->textures.size(); i++)
+      desc.push_back(DevTexture{ reinterpret_cast<const v4*>(c->dTexels.p + offs[i]), c->textures[i].width, c->textures[i].height });
+    HIPCHK(c, c->dTextures.upload(desc, c->stream), "upload texture descriptors");
+    HIPCHK(c, hipStreamSynchronize(c->stream), "sync texture upload");   // staging vectors die here
+  }
   lbvh_free(&c->bvh);
   if (nFaces > 0) {
+    if (c->anyUV) HIPCHK(c, c->dFaceUV.upload(c->faceUV, c->stream), "upload face texcoords");
     HIPCHK(c, c->dFacePos.upload(c->facePos, c->stream), "upload face positions");
     HIPCHK(c, c->dFaceNrm.upload(c->faceNrm, c->stream), "upload face normals");
     HIPCHK(c, c->dFaceHasNrm.upload(c->faceHasNrm, c->stream), "upload face flags");

@@ -43,9 +43,10 @@ struct alignas(16) SlotCold {           // 6 x 16 B
   float radx, rady, radz; int mat;
   float Nx, Ny, Nz; int light;
   float Vx, Vy, Vz; float pendInv;
-  float pwx, pwy, pwz; int pad0;
+  float pwx, pwy, pwz; float cdx;      // cd*: PathState::cdlin (textured materials)
+  float cdy, cdz; int pad1, pad2;
 };
-static_assert(sizeof(SlotCold) == 96, "SlotCold layout");
+static_assert(sizeof(SlotCold) == 112, "SlotCold layout");
 
 struct LaneStack16 {
   int* lds; int* ovf; int ovfStride;
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(kBlockThreads, PT_POOL_WAVES_PER_SIMD) pt_pool
       ps.mode = c.mode; ps.pixel = c.pixel; ps.item = c.item; ps.depth = c.depth; ps.seed = c.seed;
       ps.thr = mk3(c.thrx, c.thry, c.thrz); ps.rad = mk3(c.radx, c.rady, c.radz); ps.mat = c.mat;
       ps.N = mk3(c.Nx, c.Ny, c.Nz); ps.light = c.light; ps.V = mk3(c.Vx, c.Vy, c.Vz); ps.pendInv = c.pendInv;
-      ps.pendW = mk3(c.pwx, c.pwy, c.pwz); ps.accum = mk3(0, 0, 0);
+      ps.pendW = mk3(c.pwx, c.pwy, c.pwz); ps.accum = mk3(0, 0, 0); ps.cdlin = mk3(c.cdx, c.cdy, c.cdz);
       ps.o = mk3(h0.x, h0.y, h0.z); ps.tmax = h0.w; ps.d = mk3(h1.x, h1.y, h1.z); ps.kind = f2i(h1.w); ps.tmin = sc.epsT;
       // hit record -> the Trav fields on_result() consumes
       res.tbest = h2.x; res.beta = h2.y; res.gamma = h2.z; res.att = mk3(h2.x, h2.y, h2.z);
@@ -183,7 +184,8 @@ __global__ void __launch_bounds__(kBlockThreads, PT_POOL_WAVES_PER_SIMD) pt_pool
       c.mode = ps.mode; c.pixel = ps.pixel; c.item = ps.item; c.depth = ps.depth; c.seed = ps.seed;
       c.thrx = ps.thr.x; c.thry = ps.thr.y; c.thrz = ps.thr.z; c.radx = ps.rad.x; c.rady = ps.rad.y; c.radz = ps.rad.z; c.mat = ps.mat;
       c.Nx = ps.N.x; c.Ny = ps.N.y; c.Nz = ps.N.z; c.light = ps.light; c.Vx = ps.V.x; c.Vy = ps.V.y; c.Vz = ps.V.z; c.pendInv = ps.pendInv;
-      c.pwx = ps.pendW.x; c.pwy = ps.pendW.y; c.pwz = ps.pendW.z; c.pad0 = 0;
+      c.pwx = ps.pendW.x; c.pwy = ps.pendW.y; c.pwz = ps.pendW.z; c.cdx = ps.cdlin.x;
+      c.cdy = ps.cdlin.y; c.cdz = ps.cdlin.z; c.pad1 = 0; c.pad2 = 0;
       cold[slot] = c;
       if (ps.mode == M_TRACE) {
         v4 h0, h1;

@@ -95,7 +95,8 @@ PT_HD_BRDF float disney_pdf(const DevMaterial& m, v3 N, v3 L, v3 H) {
 }
 
 // disney.h:48-91
-PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 N, v3 L, v3 V, v3 H) {
+// Cdlin/Cspec0/Csheen: the material's constants, or the per-hit ones of a textured material
+PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 Cdlin, v3 Cspec0, v3 Csheen, v3 N, v3 L, v3 V, v3 H) {
   Onb onb = make_onb(N);
   float NdotL = dot(N, L), NdotV = dot(N, V), NdotH = dot(N, H), LdotH = dot(L, H);
   const v3 one = mk3(1.f, 1.f, 1.f);
@@ -113,14 +114,14 @@ PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 N, v3 L, v3 V, v3 H) {
   v3 Y = normalize(cross(N, X));
   float Ds = GTR2Aniso(NdotH, dot(H, X), dot(H, Y), m.ax, m.ay);
   float FH = schlickFresnel(LdotH);
-  v3 Fs = lerp(m.Cspec0, one, FH);
+  v3 Fs = lerp(Cspec0, one, FH);
   float Gs = smithGGgxAniso(NdotL, dot(L, X), dot(L, Y), m.ax, m.ay) *
              smithGGgxAniso(NdotV, dot(V, X), dot(V, Y), m.ax, m.ay);
-  v3 Fsheen = m.Csheen * (FH * m.sheen);
+  v3 Fsheen = Csheen * (FH * m.sheen);
   float Dr = GTR1_cc(NdotH, m);
   float Fr = lerp(0.04f, 1.f, FH);
   float Gr = smithGGgx(NdotL, 0.25f) * smithGGgx(NdotV, 0.25f);
-  v3 diffuse = (m.Cdlin * ((1.0f / kPi) * lerp(Fd, ss, m.subsurface)) + Fsheen) * m.oneMinusMetallic;
+  v3 diffuse = (Cdlin * ((1.0f / kPi) * lerp(Fd, ss, m.subsurface)) + Fsheen) * m.oneMinusMetallic;
   v3 spec = (Fs * Gs) * Ds;
   float cc = 0.25f * m.clearcoat * Gr * Fr * Dr;
   return (diffuse + spec) + cc;

@@ -74,6 +74,6 @@ PT_HD void refine_hitpoint(v3 original, v3 direction, v3 normal, v3 p, v3& back,
   else                               { back = offset_pt(refined, -normal); front = offset_pt(refined, normal); }
 }
 
-struct HitAttr { v3 geoNormal, shadingNormal, front, back; int mat; };
+struct HitAttr { v3 geoNormal, shadingNormal, front, back; int mat; float texu, texv; };
 
 }  // namespace pt

@@ -15,6 +15,7 @@
 #include "pt_rng.h"
 #include "pt_geom.h"
 #include "pt_disney.h"
+#include "pt_texture.h"
 
 namespace pt {
 
@@ -49,6 +50,7 @@ struct PathState {
   v3 o, d; float tmin, tmax; int kind;    // the ray in flight
   v3 N, V; int mat; int light;            // Disney hit context while its lights are looped
   v3 pendW; float pendInv;                // weight of the shadow ray in flight
+  v3 cdlin;                               // srgb2lin(texture colour) of the hit (textured Disney materials only)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -249,12 +251,14 @@ PT_HD void hit_attributes(const SceneView& sc, const PathState& ps, const Trav& 
     const v3 p = ray_at(ps.o, ps.d, t);
     h.geoNormal = normalize(p - s.center);
     h.shadingNormal = h.geoNormal;
+    h.texu = 0.f; h.texv = 0.f;                                 // Geometry.cu:37
     h.front = p; h.back = p;
     h.mat = sc.sphereMat[tv.bestPrim];
   } else if (tv.bestPrim < sc.nSpheres + sc.nQuads) {
     const DevQuad* q = sc.quads + (tv.bestPrim - sc.nSpheres);
     const v3 n = xyz(q->plane);
     h.geoNormal = n; h.shadingNormal = n;
+    h.texu = 0.f; h.texv = 0.f;                                 // the quad program writes no texcoord
     h.front = ray_at(ps.o, ps.d, t); h.back = h.front;
     h.mat = q->mat;
   } else {
@@ -262,6 +266,15 @@ PT_HD void hit_attributes(const SceneView& sc, const PathState& ps, const Trav& 
     const TriShade* sp = sc.triShade + tv.bestTri;
     const v3 p0 = tp->p0, e0 = tp->e0, e1 = tp->e1;
     h.mat = tp->mat;
+    h.texu = 0.f; h.texv = 0.f;
+    if (sc.triUV != nullptr && sc.mats[h.mat].albedoTex != 0) {               // Geometry.cu:141-148
+      const TriUV* up = sc.triUV + tp->prim;
+      if (up->hasUV) {
+        const float w0 = 1.f - tv.beta - tv.gamma;
+        h.texu = (up->u1 * tv.beta + up->u2 * tv.gamma) + up->u0 * w0;
+        h.texv = (up->v1 * tv.beta + up->v2 * tv.gamma) + up->v0 * w0;
+      }
+    }
     h.geoNormal = normalize(cross(e1, e0));
     if (sp->hasNormals) {
       const v3 n0 = sp->n0, n1 = sp->n1, n2 = sp->n2;
@@ -322,7 +335,12 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
   } else if (m.kind == MAT_GLASS) {                             // Material.cu:72-110
     glass_body<CNT>(sc, ps, m.refIdx, m.albedo, h, ct);
   } else {                                                      // disney, Material.cu:118-223
-    if (m.brdfType == BRDF_GLASS) { glass_body<CNT>(sc, ps, 1.45f, m.color, h, ct); return; }
+    v3 baseColor = m.color;
+    if (m.albedoTex != 0) {                                     // Material.cu:128-132
+      baseColor = xyz(tex2d(sc.textures[m.albedoTex - 1], h.texu, h.texv));
+      ps.cdlin = srgb2lin(baseColor);
+    }
+    if (m.brdfType == BRDF_GLASS) { glass_body<CNT>(sc, ps, 1.45f, baseColor, h, ct); return; }
     ps.N = faceforward(h.shadingNormal, -ps.d, h.geoNormal);
     ps.V = -ps.d;
     ps.mat = h.mat;
@@ -375,8 +393,13 @@ PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
   }
   if (choice == 0) { end_sample(ps); return; }
 
+  v3 Cdlin = m.Cdlin, Cspec0 = m.Cspec0, Csheen = m.Csheen;
+  if (m.albedoTex != 0) {
+    Cdlin = ps.cdlin;
+    disney_color_constants(Cdlin, m.specular, m.specularTint, m.sheenTint, m.metallic, Cspec0, Csheen);
+  }
   const float pdf = disney_pdf(m, ps.N, L, H);
-  const v3 brdf = disney_eval(m, ps.N, L, ps.V, H);
+  const v3 brdf = disney_eval(m, Cdlin, Cspec0, Csheen, ps.N, L, ps.V, H);
 
   if (choice == 1) {
     if (lightPdf > 0 && pdf > 0) {

@@ -43,6 +43,13 @@ struct alignas(16) TriShade {
 };
 static_assert(sizeof(TriShade) == 48, "TriShade must be 48 bytes");
 
+// texcoords of one face (upload order, indexed by Tri48::prim); fetched only when the hit material is textured
+struct alignas(16) TriUV { float u0, v0, u1, v1, u2, v2; int hasUV; int pad; };
+static_assert(sizeof(TriUV) == 32, "TriUV must be 32 bytes");
+
+// RT_FORMAT_FLOAT4 texture buffer behind a sampler (MinimalOptiX.cpp:449-474); row 0 = v 0
+struct DevTexture { const v4* texels; int width, height; };
+
 struct alignas(16) DevQuad {   // QuadParams (Structures.h:28) + material
   v4 plane;
   v3 v1; int mat;
@@ -86,8 +93,11 @@ struct alignas(16) DevMaterial {
   float ax, ay;                      // max(.001, roughness^2/aspect), max(.001, roughness^2*aspect)
   float ccA2m1;                      // ccAlpha^2 - 1
   float ccPiLogA2;                   // M_PIf * logf(ccAlpha^2)
+  // textured materials (albedoTex != 0) derive Cdlin/Cspec0/Csheen per hit from the sampled base colour
+  int albedoTex;                     // 0 == RT_TEXTURE_ID_NULL, else textures[albedoTex-1]
+  float specular, specularTint, sheenTint;
 };
-static_assert(sizeof(DevMaterial) == 144, "DevMaterial layout");
+static_assert(sizeof(DevMaterial) == 160, "DevMaterial layout");
 
 struct Cam { v3 origin, horizontal, vertical, scrLowerLeftCorner, u, v; float lensRadius; };
 
@@ -104,6 +114,8 @@ struct SceneView {
   int anyDisneyAnalytic;          // any sphere/quad carries a Disney material (shadow any-hit applies)
   int nTris; int rootRef;         // rootRef: node index, leaf ref or kEmptyRef
   const Node64* nodes; const Tri48* tris; const TriShade* triShade;
+  const TriUV* triUV;             // per face in upload order, or nullptr (no mesh has texcoords)
+  int nTextures; const DevTexture* textures;
 };
 
 }  // namespace pt

@@ -5,14 +5,14 @@
 #include <math.h>
 #include <string.h>
 #include "../../include/moptix.h"
-#include "pt_types.h"
+#include "pt_texture.h"
 
 namespace pt {
 
 inline v3 to_v3(const moptix_float3& f) { return mk3(f.x, f.y, f.z); }
 
 // DisneyParams -> DevMaterial incl. the per-material constants of disney.h:49-77 / :32-38.
-// Same formulas, same order as the reference evaluates per call (AC6: powf/logf = host libm).
+// Same formulas, same order as the reference evaluates per call (AC6: logf = host libm, x^2.2 through double).
 inline DevMaterial make_dev_material(const moptix_material& m) {
   DevMaterial d;
   memset(&d, 0, sizeof(d));
@@ -27,12 +27,9 @@ inline DevMaterial make_dev_material(const moptix_material& m) {
     d.emission = to_v3(p.emission);
     d.metallic = p.metallic; d.roughness = p.roughness; d.subsurface = p.subsurface;
     d.sheen = p.sheen; d.clearcoat = p.clearcoat;
-    const v3 one = mk3(1.f, 1.f, 1.f);
-    d.Cdlin = mk3(powf(d.color.x, 2.2f), powf(d.color.y, 2.2f), powf(d.color.z, 2.2f));   // srgb2lin
-    const float Cdlum = dot(d.Cdlin, mk3(0.3f, 0.6f, 0.1f));
-    const v3 Ctint = Cdlum > 0.f ? d.Cdlin / Cdlum : one;
-    d.Cspec0 = lerp(lerp(one, Ctint, p.specularTint) * (p.specular * 0.08f), d.Cdlin, p.metallic);
-    d.Csheen = lerp(one, Ctint, p.sheenTint);
+    d.albedoTex = p.albedoID; d.specular = p.specular; d.specularTint = p.specularTint; d.sheenTint = p.sheenTint;
+    d.Cdlin = srgb2lin(d.color);                                           // AC6
+    disney_color_constants(d.Cdlin, p.specular, p.specularTint, p.sheenTint, p.metallic, d.Cspec0, d.Csheen);
     d.oneMinusMetallic = 1.0f - p.metallic;
     d.diffuseRatio = 0.5f * (1.0f - p.metallic);
     d.specAlpha = fmaxf(0.001f, p.roughness);

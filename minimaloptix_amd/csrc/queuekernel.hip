@@ -46,11 +46,11 @@ struct alignas(16) SlotCold {           // 9 x 16 B, HBM, private to the pool
   float radx, rady, radz; int mat;
   float Nx, Ny, Nz; int light;
   float Vx, Vy, Vz; float pendInv;
-  float pwx, pwy, pwz; int pad0;
+  float pwx, pwy, pwz; float cdx;      // cd*: PathState::cdlin (textured materials), in the spare words of three rows
   // "warm" ray state: needed by leaf passes and shading, not by the node loop
   float dx, dy, dz, tmax;
-  int kind, bestTri, bestPrim, pad1;
-  float c0, c1, c2; int pad2;          // beta, gamma | shadow attenuation
+  int kind, bestTri, bestPrim; float cdy;
+  float c0, c1, c2; float cdz;         // beta, gamma | shadow attenuation
 };
 static_assert(sizeof(SlotCold) == 144, "SlotCold layout");
 
@@ -262,10 +262,10 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       W.nodeA[slot].w = tv.tbest;
       W.nodeB[slot].w = i2f(tv.node);
       W.stack[slot][0] = tv.sp | ((ps.kind == RK_SHADOW || tv.bestPrim >= 0) ? kShadeFlag : 0);
-      i4 o1; o1.x = ps.kind; o1.y = tv.bestTri; o1.z = tv.bestPrim; o1.w = 0;
+      i4 o1; o1.x = ps.kind; o1.y = tv.bestTri; o1.z = tv.bestPrim; o1.w = w1.w;
       v4 o2;
       if (ps.kind == RK_SHADOW) { o2.x = tv.att.x; o2.y = tv.att.y; o2.z = tv.att.z; } else { o2.x = tv.beta; o2.y = tv.gamma; o2.z = 0.f; }
-      o2.w = 0.f;
+      o2.w = w2.w;
       SlotCold* cw = cold + slot;
       // most leaf visits find nothing nearer: only write the hit record back when it changed
       if (o1.y != w1.y || o1.z != w1.z || o2.x != w2.x || o2.y != w2.y || o2.z != w2.z) {
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       ps.mode = c.mode; ps.pixel = c.pixel; ps.item = c.item; ps.depth = c.depth; ps.seed = c.seed;
       ps.thr = mk3(c.thrx, c.thry, c.thrz); ps.rad = mk3(c.radx, c.rady, c.radz); ps.mat = c.mat;
       ps.N = mk3(c.Nx, c.Ny, c.Nz); ps.light = c.light; ps.V = mk3(c.Vx, c.Vy, c.Vz); ps.pendInv = c.pendInv;
-      ps.pendW = mk3(c.pwx, c.pwy, c.pwz); ps.accum = mk3(0, 0, 0);
+      ps.pendW = mk3(c.pwx, c.pwy, c.pwz); ps.accum = mk3(0, 0, 0); ps.cdlin = mk3(c.cdx, c.cdy, c.cdz);
       ps.o = mk3(na.x, na.y, na.z); ps.tmax = c.tmax; ps.d = mk3(c.dx, c.dy, c.dz); ps.kind = c.kind; ps.tmin = sc.epsT;
       res.tbest = na.w; res.bestTri = c.bestTri; res.bestPrim = c.bestPrim;
       res.beta = c.c0; res.gamma = c.c1; res.att = mk3(c.c0, c.c1, c.c2);
@@ -320,9 +320,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       c.mode = ps.mode; c.pixel = ps.pixel; c.item = ps.item; c.depth = ps.depth; c.seed = ps.seed;
       c.thrx = ps.thr.x; c.thry = ps.thr.y; c.thrz = ps.thr.z; c.radx = ps.rad.x; c.rady = ps.rad.y; c.radz = ps.rad.z; c.mat = ps.mat;
       c.Nx = ps.N.x; c.Ny = ps.N.y; c.Nz = ps.N.z; c.light = ps.light; c.Vx = ps.V.x; c.Vy = ps.V.y; c.Vz = ps.V.z; c.pendInv = ps.pendInv;
-      c.pwx = ps.pendW.x; c.pwy = ps.pendW.y; c.pwz = ps.pendW.z; c.pad0 = 0;
+      c.pwx = ps.pendW.x; c.pwy = ps.pendW.y; c.pwz = ps.pendW.z; c.cdx = ps.cdlin.x;
       c.dx = ps.d.x; c.dy = ps.d.y; c.dz = ps.d.z; c.tmax = ps.tmax;
-      c.kind = ps.kind; c.bestTri = -1; c.bestPrim = -1; c.pad1 = 0; c.c0 = 0.f; c.c1 = 0.f; c.c2 = 0.f; c.pad2 = 0;
+      c.kind = ps.kind; c.bestTri = -1; c.bestPrim = -1; c.cdy = ps.cdlin.y; c.c0 = 0.f; c.c1 = 0.f; c.c2 = 0.f; c.cdz = ps.cdlin.z;
       if (ps.mode == M_TRACE) {
         // new ray: analytic primitives + traversal set-up happen here, on the full batch
         Trav tv;

@@ -4,6 +4,7 @@
 #include <exception>
 #include <string>
 
+#include "image_io.h"
 #include "minimal_optix.h"
 #include "obj_loader.h"
 #include "scene_desc.h"
@@ -39,6 +40,7 @@ static void counts(const SceneDesc& d, mohost_scene_sizes* o) {
   memset(o, 0, sizeof(*o));
   o->nMaterials = (int32_t)d.materials.size(); o->nSpheres = (int32_t)d.spheres.size(); o->nQuads = (int32_t)d.quads.size();
   o->nLights = (int32_t)d.lights.size(); o->nMeshes = (int32_t)d.meshes.size(); o->nWarnings = (int32_t)d.warnings.size();
+  o->nTextures = (int32_t)d.textures.size();
   for (const MeshDesc& m : d.meshes) {
     o->nVerts += (int32_t)(m.positions.size() / 3); o->nNormals += (int32_t)(m.normals.size() / 3);
     o->nTexcoords += (int32_t)(m.texcoords.size() / 2); o->nFaces += (int32_t)(m.vIdx.size() / 3);
@@ -90,6 +92,42 @@ int mohost_scene_copy(mohost_scene s, moptix_material* materials, moptix_sphere_
       if (faceMat) faceMat[fOff + f] = m.matId;
     }
     vOff += nv; nOff += nn; fOff += nf;
+  }
+  return MOPTIX_OK;
+}
+
+int mohost_scene_copy_texcoords(mohost_scene s, float* texcoords, int32_t* tIdx) {
+  if (!s) return MOPTIX_ERR_INVALID;
+  size_t tOff = 0, fOff = 0;
+  for (const MeshDesc& m : s->desc.meshes) {
+    const size_t nt = m.texcoords.size() / 2, nf = m.vIdx.size() / 3;
+    if (texcoords && nt) memcpy(texcoords + 2 * tOff, m.texcoords.data(), m.texcoords.size() * sizeof(float));
+    for (size_t f = 0; f < nf; f++) {
+      const bool hasT = nt > 0 && m.tIdx[3 * f] >= 0 && m.tIdx[3 * f + 1] >= 0 && m.tIdx[3 * f + 2] >= 0;
+      for (int k = 0; k < 3; k++) if (tIdx) tIdx[3 * (fOff + f) + k] = hasT ? m.tIdx[3 * f + k] + (int32_t)tOff : -1;
+    }
+    tOff += nt; fOff += nf;
+  }
+  return MOPTIX_OK;
+}
+
+int mohost_scene_texture(mohost_scene s, int32_t i, int32_t* width, int32_t* height, float* rgba) {
+  if (!s || i < 0 || i >= (int32_t)s->desc.textures.size()) { g_err = "no such texture"; return MOPTIX_ERR_INVALID; }
+  const TextureDesc& t = s->desc.textures[i];
+  if (width) *width = t.width;
+  if (height) *height = t.height;
+  if (rgba) memcpy(rgba, t.rgba.data(), t.rgba.size() * sizeof(float));
+  return MOPTIX_OK;
+}
+
+int mohost_read_image(const char* path, int32_t* width, int32_t* height, uint8_t* rgb, uint64_t rgbCapacity) {
+  int w = 0, h = 0; std::vector<uint8_t> px; std::string err;
+  if (!path || !readImage(path, w, h, px, err)) { g_err = path ? err : "null path"; return MOPTIX_ERR_INVALID; }
+  if (width) *width = w;
+  if (height) *height = h;
+  if (rgb) {
+    if (rgbCapacity < px.size()) { g_err = "image buffer too small"; return MOPTIX_ERR_INVALID; }
+    memcpy(rgb, px.data(), px.size());
   }
   return MOPTIX_OK;
 }

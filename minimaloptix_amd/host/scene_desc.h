@@ -31,6 +31,12 @@ struct MeshDesc {                 // one tinyobj shape (MinimalOptiX.cpp:392-441
   std::string source;
 };
 
+struct TextureDesc {              // one TextureSampler + its float4 buffer (MinimalOptiX.cpp:444-479)
+  std::string name;               // file name relative to the scene folder (texNameSamplerMap key)
+  int32_t width = 0, height = 0;
+  std::vector<float> rgba;        // 4*width*height, row 0 = bottom image row
+};
+
 struct SceneDesc {
   std::string name;
   moptix_params params{};         // W,H, depth, eps, bgColor, camParams
@@ -40,6 +46,7 @@ struct SceneDesc {
   std::vector<moptix_quad_params> quads;     std::vector<int32_t> quadMat;
   std::vector<moptix_light_params> lights;   // NEE light list (context["lights"])
   std::vector<MeshDesc> meshes;
+  std::vector<TextureDesc> textures;         // DisneyParams.albedoID = index + 1
   Aabb aabb;
   size_t nVertices = 0, nFaces = 0;          // MinimalOptiX.h:86-87
   std::vector<std::string> warnings;

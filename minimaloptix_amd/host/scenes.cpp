@@ -8,6 +8,7 @@
 #include <random>
 #include <stdexcept>
 
+#include "image_io.h"
 #include "obj_loader.h"
 #include "scene_file.h"
 
@@ -123,8 +124,25 @@ static void loadFileScene(SceneDesc& s, const std::string& baseSceneFolder, cons
       throw std::logic_error("Cannot load mesh file.");                       // :386-389
     }
     if (matIndex >= scene.materials.size()) throw std::logic_error("mesh entry without material: " + scene.meshNames[i]);
-    if (!scene.textures[matIndex].empty())
-      s.warnings.push_back("albedoTex '" + scene.textures[matIndex] + "' ignored (textures: SURVEY 8f)");
+    if (!scene.textures[matIndex].empty()) {                                  // :445-479 one sampler per file name
+      const std::string& texName = scene.textures[matIndex];
+      int texId = 0;
+      for (size_t t = 0; t < s.textures.size(); t++) if (s.textures[t].name == texName) texId = (int)t + 1;
+      if (texId == 0) {
+        int tw = 0, th = 0; std::vector<uint8_t> rgb; std::string ierr;
+        if (readImage(sceneFolder + texName, tw, th, rgb, ierr)) {
+          TextureDesc td; td.name = texName; td.width = tw; td.height = th;
+          imageToTextureRGBA(rgb, tw, th, td.rgba);
+          s.textures.push_back(std::move(td));
+          texId = (int)s.textures.size();
+        } else {
+          // QImage yields a null image here and the reference goes on to create a 0x0 buffer; we keep the
+          // material's constant colour instead and say so
+          s.warnings.push_back("albedoTex ignored: " + ierr);
+        }
+      }
+      scene.materials[matIndex].albedoID = texId;
+    }
     const int matId = s.addMaterial(disneyMaterial(scene.materials[matIndex]));   // :482-485
     for (size_t sh = 0; sh < shapes.size(); sh++) {                           // :390-442 one Geometry per shape
       MeshDesc m;
@@ -384,6 +402,10 @@ int upload(const SceneDesc& s, moptix_context ctx) {
   int rc;
   if ((rc = moptix_clear_scene(ctx)) != MOPTIX_OK) return rc;
   if ((rc = moptix_set_params(ctx, &s.params)) != MOPTIX_OK) return rc;
+  for (const TextureDesc& t : s.textures) {
+    int32_t id = 0;
+    if ((rc = moptix_add_texture(ctx, t.rgba.data(), t.width, t.height, &id)) != MOPTIX_OK) return rc;
+  }
   for (const moptix_material& m : s.materials) {
     int32_t id = -1;
     if ((rc = moptix_add_material(ctx, &m, &id)) != MOPTIX_OK) return rc;

@@ -47,6 +47,10 @@ class OrcCam(C.Structure):
                 ("u", f3), ("v", f3), ("lensRadius", C.c_float)]
 
 
+class OrcTexture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgba", C.POINTER(C.c_float))]
+
+
 class OrcScene(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("cam", OrcCam), ("bgColor", f3),
                 ("rayMaxDepth", C.c_int32), ("rayMinIntensity", C.c_float), ("rayEpsilonT", C.c_float),
@@ -60,7 +64,7 @@ class OrcScene(C.Structure):
                 ("nFaces", C.c_int32),
                 ("vIdx", C.POINTER(C.c_int32)), ("nIdx", C.POINTER(C.c_int32)),
                 ("tIdx", C.POINTER(C.c_int32)), ("faceMat", C.POINTER(C.c_int32)),
-                ("bruteForceTris", C.c_int32)]
+                ("bruteForceTris", C.c_int32), ("nTextures", C.c_int32), ("textures", C.POINTER(OrcTexture))]
 
 
 class OrcStats(C.Structure):
@@ -128,6 +132,8 @@ def lib():
         L.orc_closest_hit.argtypes = [C.POINTER(OrcScene), f3, f3, C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.orc_move_sphere.restype = None
         L.orc_move_sphere.argtypes = [f3, C.c_float, f3, C.c_float]
+        L.orc_tex2d.argtypes = [C.POINTER(OrcTexture), C.c_float, C.c_float, C.c_float * 4]
+        L.orc_tex2d.restype = None
         L.orc_num_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -228,6 +234,14 @@ class Scene:
         s.vIdx, s.nIdx, s.tIdx, s.faceMat = (_ptr(self._vi, C.c_int32), _ptr(self._ni, C.c_int32),
                                             _ptr(self._ti, C.c_int32), _ptr(self._fm, C.c_int32))
         s.bruteForceTris = 1 if brute_force_tris else 0
+        # textures: list of (H, W, 4) float32 arrays, row 0 = v 0; material albedoID = index + 1
+        self._texpx = [np.ascontiguousarray(np.asarray(t, np.float32)) for t in desc.get("textures", [])]
+        self._textures = (OrcTexture * max(1, len(self._texpx)))()
+        for i, t in enumerate(self._texpx):
+            assert t.ndim == 3 and t.shape[2] == 4
+            self._textures[i].height, self._textures[i].width = t.shape[0], t.shape[1]
+            self._textures[i].rgba = _ptr(t, C.c_float)
+        s.nTextures, s.textures = len(self._texpx), C.cast(self._textures, C.POINTER(OrcTexture))
         self.c = s
         self.width, self.height = s.width, s.height
 

@@ -222,7 +222,32 @@ static float smithGGgxAniso(float NdotV, float VdotX, float VdotY, float ax, flo
   return 1.0f / (NdotV + sqrtf(sqr(VdotX * ax) + sqr(VdotY * ay) + sqr(NdotV)));
 }
 /* utils_device.h:173-175; AC6 */
-static f3 srgb2lin(f3 v) { return mk3(powf(v.x, 2.2f), powf(v.y, 2.2f), powf(v.z, 2.2f)); }
+static inline float pow22(float x) { return (float)pow((double)x, (double)2.2f); }
+static f3 srgb2lin(f3 v) { return mk3(pow22(v.x), pow22(v.y), pow22(v.z)); }
+
+/* rtTex2D<float4>(id, u, v) with the sampler the reference creates (MinimalOptiX.cpp:449-474): repeat wrap,
+ * normalized coordinates, bilinear filter.  CUDA texture units (which OptiX 5 uses) place texel centres at +0.5
+ * and interpolate with weights quantised to 8 fractional bits. */
+static inline int wrapi(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+static void tex2d(const OrcTexture* t, float u, float v, float out[4]) {
+  const float x = (u - floorf(u)) * (float)t->width - 0.5f;
+  const float y = (v - floorf(v)) * (float)t->height - 0.5f;
+  const float fx = floorf(x), fy = floorf(y);
+  const float ax = (float)(int)((x - fx) * 256.0f + 0.5f) * (1.0f / 256.0f);
+  const float ay = (float)(int)((y - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
+  const int i0 = wrapi((int)fx, t->width), i1 = wrapi((int)fx + 1, t->width);
+  const int j0 = wrapi((int)fy, t->height), j1 = wrapi((int)fy + 1, t->height);
+  const float* t00 = t->rgba + 4 * ((size_t)j0 * t->width + i0);
+  const float* t10 = t->rgba + 4 * ((size_t)j0 * t->width + i1);
+  const float* t01 = t->rgba + 4 * ((size_t)j1 * t->width + i0);
+  const float* t11 = t->rgba + 4 * ((size_t)j1 * t->width + i1);
+  for (int k = 0; k < 4; k++) {
+    const float lo = t00[k] + ax * (t10[k] - t00[k]);
+    const float hi = t01[k] + ax * (t11[k] - t01[k]);
+    out[k] = lo + ay * (hi - lo);
+  }
+}
+void orc_tex2d(const OrcTexture* t, float u, float v, float out[4]) { tex2d(t, u, v, out); }
 /* utils_device.h:182-185 */
 static float powerHeuristic(float a, float b) { float t = a * a; return t / (b * b + t); }
 
@@ -429,6 +454,7 @@ static void bvh_free(TriBVH* b) { if (!b) return; free(b->nodes); free(b->order)
 typedef struct {
   float t; int32_t prim; int32_t mat;
   f3 geoNormal, shadingNormal, frontHitPoint, backHitPoint;
+  float texu, texv;     /* texcoord attribute (Geometry.cu:37, 141-148) */
 } Hit;
 
 typedef struct {
@@ -525,7 +551,7 @@ static int find_closest(Ctx* cx, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
     }
   }
   if (bestPrim < 0) return 0;
-  hit->t = best; hit->prim = bestPrim;
+  hit->t = best; hit->prim = bestPrim; hit->texu = 0.f; hit->texv = 0.f;
   if (bestPrim < sc->nSpheres) {                       /* Geometry.cu:30-53 */
     const OrcSphere* s = &sc->spheres[bestPrim];
     (void)bestRoot;
@@ -549,6 +575,14 @@ static int find_closest(Ctx* cx, f3 o, f3 d, float tmin, float tmax, Hit* hit) {
     } else {
       f3 n0 = ld3(sc->normals + 3 * (size_t)ni[0]), n1 = ld3(sc->normals + 3 * (size_t)ni[1]), n2 = ld3(sc->normals + 3 * (size_t)ni[2]);
       hit->shadingNormal = norm3(add3(add3(scl3(n1, bBeta), scl3(n2, bGamma)), scl3(n0, 1.f - bBeta - bGamma)));
+    }
+    const int32_t* ti = sc->tIdx ? sc->tIdx + 3 * (size_t)f : NULL;
+    if (sc->nUVs > 0 && ti && ti[0] >= 0 && ti[1] >= 0 && ti[2] >= 0) {            /* Geometry.cu:141-148 */
+      const float* t0 = sc->texcoords + 2 * (size_t)ti[0]; const float* t1 = sc->texcoords + 2 * (size_t)ti[1];
+      const float* t2 = sc->texcoords + 2 * (size_t)ti[2];
+      const float w0 = 1.0f - bBeta - bGamma;
+      hit->texu = (t1[0] * bBeta + t2[0] * bGamma) + t0[0] * w0;
+      hit->texv = (t1[1] * bBeta + t2[1] * bGamma) + t0[1] * w0;
     }
     refine_hitpoint(ray_at(o, d, best), d, hit->geoNormal, vert(sc, sc->vIdx[3 * f]), &hit->backHitPoint, &hit->frontHitPoint);
     hit->mat = sc->faceMat[f];
@@ -686,7 +720,12 @@ static void prog_disney(Ctx* cx, const OrcMaterial* m, f3 d, const Hit* h, Paylo
   f3 N = faceforward3(h->shadingNormal, neg3(d), h->geoNormal);
   f3 V = neg3(d);
   f3 L, H;
-  f3 baseColor = ld3(m->color);   /* albedoID == RT_TEXTURE_ID_NULL: textures are a "next" row */
+  f3 baseColor = ld3(m->color);
+  if (m->albedoID != 0 && m->albedoID <= sc->nTextures) {      /* Material.cu:128-132 */
+    float tc[4];
+    tex2d(&sc->textures[m->albedoID - 1], h->texu, h->texv, tc);
+    baseColor = mk3(tc[0], tc[1], tc[2]);
+  }
   if (m->brdfType == ORC_BRDF_GLASS) { glass_body(cx, 1.45f, baseColor, d, h, p); return; }
 
   f3 direct = mk3(0.f, 0.f, 0.f);

@@ -26,7 +26,8 @@
  *   AC4 every other C operator is one IEEE binary32 operation, in source order
  *       (compile with -ffp-contract=off)
  *   AC5 sinf/cosf(x) := (float)sin((double)x), (float)cos((double)x)
- *   AC6 powf/logf of per-material constants are evaluated with the host libm
+ *   AC6 logf of per-material constants is evaluated with the host libm; x^2.2 (srgb2lin) is
+ *       (float)pow((double)x, (double)2.2f) -- it is per-hit for textured materials
  *   AC7 point on ray  p = fmaf(t, d, o) per component
  */
 #ifndef PT_ORACLE_H
@@ -55,7 +56,7 @@ typedef struct OrcMaterial {
   float   metallic, subsurface, specular, roughness, specularTint, anisotropic;
   float   sheen, sheenTint, clearcoat, clearcoatGloss;
   int32_t brdfType;
-  int32_t albedoID;        /* 0 == RT_TEXTURE_ID_NULL; textures are out of scope */
+  int32_t albedoID;        /* 0 == RT_TEXTURE_ID_NULL, else textures[albedoID-1] */
 } OrcMaterial;
 
 typedef struct OrcSphere { float center[3]; float radius; int32_t mat; } OrcSphere;          /* Structures.h:22 */
@@ -71,6 +72,10 @@ typedef struct OrcCam {                                                         
   float origin[3], horizontal[3], vertical[3], scrLowerLeftCorner[3], u[3], v[3];
   float lensRadius;
 } OrcCam;
+
+/* RT_FORMAT_FLOAT4 texture buffer with the sampler of MinimalOptiX.cpp:449-474:
+ * RT_WRAP_REPEAT, normalized coordinates, RT_FILTER_LINEAR.  Row 0 = v 0. */
+typedef struct OrcTexture { int32_t width, height; const float* rgba; } OrcTexture;
 
 typedef struct OrcScene {
   int32_t width, height;
@@ -96,6 +101,7 @@ typedef struct OrcScene {
   const int32_t* faceMat;/* nFaces */
 
   int32_t bruteForceTris;    /* !=0: skip the oracle's BVH (validation of the BVH itself) */
+  int32_t nTextures; const OrcTexture* textures;
 } OrcScene;
 
 typedef struct OrcStats {
@@ -141,6 +147,8 @@ int   orc_intersect_triangle(const float o[3], const float d[3], float tmin, flo
                              float n[3], float* t, float* beta, float* gamma);
 /* MinimalOptiX::move (MinimalOptiX.cpp:562-585): one sphere {center[3], radius, velocity[3]} for `time` seconds */
 void  orc_move_sphere(float center[3], float radius, float velocity[3], float time);
+/* rtTex2D<float4> restated (SURVEY A1 / CUDA linear filtering with 8-bit interpolation weights) */
+void  orc_tex2d(const OrcTexture* t, float u, float v, float out[4]);
 int   orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -25,7 +25,9 @@ class HostsimScene(C.Structure):
                 ("nQuads", C.c_int32), ("quads", C.POINTER(K.QuadParams)), ("quadMat", C.POINTER(C.c_int32)),
                 ("nLights", C.c_int32), ("lights", C.POINTER(K.LightParams)),
                 ("nFaces", C.c_int32), ("facePos", C.POINTER(C.c_float)), ("faceNrm", C.POINTER(C.c_float)),
-                ("faceHasNrm", C.POINTER(C.c_int32)), ("faceMat", C.POINTER(C.c_int32))]
+                ("faceHasNrm", C.POINTER(C.c_int32)), ("faceMat", C.POINTER(C.c_int32)),
+                ("faceUV", C.POINTER(C.c_float)), ("faceHasUV", C.POINTER(C.c_int32)),
+                ("nTextures", C.c_int32), ("texSize", C.POINTER(C.c_int32)), ("texels", C.POINTER(C.POINTER(C.c_float)))]
 
 
 class HostsimBvhOut(C.Structure):
@@ -62,7 +64,14 @@ def _hostsim_scene(hs):
     s.nQuads, s.quads, s.quadMat = hs.sizes.nQuads, C.cast(f["quads"], C.POINTER(K.QuadParams)), ip(qmat)
     s.nLights, s.lights = hs.sizes.nLights, C.cast(f["lights"], C.POINTER(K.LightParams))
     s.nFaces, s.facePos, s.faceNrm, s.faceHasNrm, s.faceMat = len(fm), fpp(fp), fpp(fn), ip(has), ip(fm)
-    return s, (f, fp, fn, has, fm, smat, qmat)
+    uv, has_uv = hs.face_uvs()
+    uv = np.ascontiguousarray(uv, np.float32); has_uv = np.ascontiguousarray(has_uv, np.int32)
+    s.faceUV, s.faceHasUV = fpp(uv), ip(has_uv)
+    tex = [np.ascontiguousarray(t, np.float32) for t in f["textures"]]
+    tsz = np.ascontiguousarray([[t.shape[1], t.shape[0]] for t in tex], np.int32).reshape(-1, 2)
+    tptr = (C.POINTER(C.c_float) * max(1, len(tex)))(*[fpp(t) for t in tex])
+    s.nTextures, s.texSize, s.texels = len(tex), ip(tsz), tptr
+    return s, (f, fp, fn, has, fm, smat, qmat, uv, has_uv, tex, tsz, tptr)
 
 
 HOSTSIM_COUNTERS = ("samples", "primaryRays", "bounceRays", "shadowRays", "nodeFetches", "triTests", "closestHits",
@@ -107,3 +116,149 @@ def have_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+# ---------------------------------------------------------------------------------------------
+# textured test scene: written to disk and loaded through the .scene/.obj/image ingest
+# ---------------------------------------------------------------------------------------------
+def write_png(path, rgb, filter_type=0):
+    """Minimal PNG writer (8-bit RGB, zlib level 9 -> dynamic Huffman blocks); filter 0 (None) or 1 (Sub)."""
+    import struct, zlib
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    rows = []
+    for y in range(h):
+        row = rgb[y].reshape(-1).astype(np.int32)
+        if filter_type == 1:
+            prev = np.concatenate([np.zeros(3, np.int32), row[:-3]])
+            row = (row - prev) & 0xff
+        rows.append(bytes([filter_type]) + row.astype(np.uint8).tobytes())
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    data = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(b"".join(rows), 9)) + chunk(b"IEND", b""))
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+def test_textures():
+    """Two small deterministic images: a noisy checker (PNG) and a colour ramp (PPM)."""
+    rng = np.random.RandomState(7)
+    yy, xx = np.mgrid[0:24, 0:32]
+    checker = np.where(((xx // 4 + yy // 4) % 2)[..., None] == 0, np.uint8([230, 60, 40]), np.uint8([40, 90, 220]))
+    checker = np.clip(checker.astype(np.int32) + rng.randint(-20, 21, checker.shape), 0, 255).astype(np.uint8)
+    ramp = np.zeros((16, 16, 3), np.uint8)
+    ramp[..., 0] = (np.arange(16) * 17)[None, :]; ramp[..., 1] = (np.arange(16) * 17)[:, None]; ramp[..., 2] = 128
+    return checker, ramp
+
+
+test_textures.__test__ = False
+
+
+def write_textured_scene(root):
+    """root/cornell/{cornell.scene, *.obj, checker.png, ramp.ppm}: a box seen by the 'cornell' camera with
+    textured Disney walls (repeat-wrapped and negative texcoords), a textured glass pane (BRDF_GLASS: tint from
+    the texture, shadow any-hit from the constant colour), a textured material on a mesh WITHOUT texcoords
+    (texcoord (0,0)), an untextured mesh and one quad light."""
+    d = os.path.join(str(root), "cornell")
+    os.makedirs(d, exist_ok=True)
+    checker, ramp = test_textures()
+    write_png(os.path.join(d, "checker.png"), checker, filter_type=1)
+    with open(os.path.join(d, "ramp.ppm"), "wb") as f:
+        f.write(b"P6\n# ramp\n16 16\n255\n" + ramp.tobytes())
+
+    def quad_obj(name, p, uv=None, n=None):
+        lines = ["v %g %g %g" % tuple(q) for q in p]
+        if uv is not None:
+            lines += ["vt %g %g" % tuple(t) for t in uv]
+        if n is not None:
+            lines += ["vn %g %g %g" % tuple(n)]
+        def idx(i):
+            if n is not None:
+                return "%d/%s/1" % (i, i if uv is not None else "")
+            return "%d/%d" % (i, i) if uv is not None else "%d" % i
+        lines.append("f " + " ".join(idx(i) for i in (1, 2, 3, 4)))
+        with open(os.path.join(d, name), "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+    quad_obj("back.obj", [(-1, -1, 1), (-1, 1, 1), (1, 1, 1), (1, -1, 1)], uv=[(-0.7, -0.4), (-0.7, 1.9), (2.2, 1.9), (2.2, -0.4)], n=(0, 0, -1))
+    quad_obj("floor.obj", [(-1, -1, -1), (-1, -1, 1), (1, -1, 1), (1, -1, -1)], uv=[(0, 0), (0, 1), (1, 1), (1, 0)], n=(0, 1, 0))
+    quad_obj("left.obj", [(1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1)])                       # no texcoords, textured material
+    quad_obj("right.obj", [(-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (-1, -1, 1)], n=(1, 0, 0))    # untextured
+    quad_obj("pane.obj", [(-0.6, -1, 0.2), (-0.6, 0.3, 0.2), (0.5, 0.3, 0.0), (0.5, -1, 0.0)], uv=[(0, 0), (0, 1.5), (1.5, 1.5), (1.5, 0)])
+    scene = """
+material Back
+{
+    color 0.9 0.9 0.9
+    albedoTex checker.png
+    roughness 0.4
+    specular 0.7
+    specularTint 0.5
+    sheen 0.3
+}
+material Floor
+{
+    color 0.5 0.5 0.5
+    albedoTex ramp.ppm
+    roughness 0.15
+    metallic 0.6
+    clearcoat 0.4
+}
+material Left
+{
+    color 0.2 0.8 0.2
+    albedoTex checker.png
+}
+material Right
+{
+    color 0.8 0.3 0.2
+    roughness 0.6
+}
+material Pane
+{
+    color 0.9 0.8 0.7
+    albedoTex ramp.ppm
+    brdf 1
+}
+mesh
+{
+    file back.obj
+    material Back
+}
+mesh
+{
+    file floor.obj
+    material Floor
+}
+mesh
+{
+    file left.obj
+    material Left
+}
+mesh
+{
+    file right.obj
+    material Right
+}
+mesh
+{
+    file pane.obj
+    material Pane
+}
+light
+{
+    type Quad
+    position -0.4 0.98 -0.4
+    v1 0.4 0.98 -0.4
+    v2 -0.4 0.98 0.4
+    emission 12 12 12
+}
+"""
+    with open(os.path.join(d, "cornell.scene"), "w") as f:
+        f.write(scene)
+    return str(root) + "/"
+
+
+def textured_scene(root, width=96, height=72):
+    base = write_textured_scene(root)
+    return M.HostScene("file:cornell", width, height, base_folder=base)

@@ -29,6 +29,10 @@ struct hostsim_scene {
   const float* faceNrm;      // 9 floats per face (ignored where faceHasNrm == 0); may be NULL
   const int32_t* faceHasNrm; // may be NULL
   const int32_t* faceMat;
+  const float* faceUV;       // 6 floats per face (u0 v0 u1 v1 u2 v2); may be NULL
+  const int32_t* faceHasUV;  // may be NULL
+  int32_t nTextures; const int32_t* texSize;   // width,height per texture
+  const float* const* texels;                  // nTextures pointers to 4*w*h floats
 };
 
 struct hostsim_bvh_out {      // caller-allocated: nodes >= max(1,nFaces-1)*64 B, tris nFaces*48 B
@@ -154,6 +158,7 @@ struct LocalStack {
 struct HostScene {
   std::vector<DevMaterial> mats; std::vector<DevSphere> spheres; std::vector<int> sphereMat;
   std::vector<DevQuad> quads; std::vector<DevLight> lights; HostBVH bvh; SceneView view;
+  std::vector<TriUV> faceUV; std::vector<DevTexture> textures;
 };
 
 static void make_scene(const hostsim_scene& s, int leafSize, HostScene& hs) {
@@ -176,6 +181,19 @@ static void make_scene(const hostsim_scene& s, int leafSize, HostScene& hs) {
   for (int i = 0; i < s.nQuads; i++) if (hs.mats[s.quadMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
   v.nTris = s.nFaces; v.rootRef = hs.bvh.rootRef;
   v.nodes = hs.bvh.nodes.data(); v.tris = hs.bvh.tris.data(); v.triShade = hs.bvh.shade.data();
+  bool anyUV = false;
+  for (int f = 0; f < s.nFaces; f++) {
+    TriUV uv; memset(&uv, 0, sizeof(uv));
+    if (s.faceUV && s.faceHasUV && s.faceHasUV[f]) {
+      const float* q = s.faceUV + 6 * (size_t)f;
+      uv.u0 = q[0]; uv.v0 = q[1]; uv.u1 = q[2]; uv.v1 = q[3]; uv.u2 = q[4]; uv.v2 = q[5]; uv.hasUV = 1; anyUV = true;
+    }
+    hs.faceUV.push_back(uv);
+  }
+  v.triUV = anyUV ? hs.faceUV.data() : nullptr;
+  for (int t = 0; t < s.nTextures; t++)
+    hs.textures.push_back(DevTexture{ reinterpret_cast<const v4*>(s.texels[t]), s.texSize[2 * t], s.texSize[2 * t + 1] });
+  v.nTextures = s.nTextures; v.textures = hs.textures.data();
 }
 
 }  // namespace

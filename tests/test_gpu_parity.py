@@ -227,3 +227,53 @@ def test_odd_frame_sizes_and_partitions(gpu_ctx):
     finally:
         gpu_ctx.set_partition(0, 1)
     assert np.array_equal(parts, whole)                    # tile split is bit-identical to one GPU
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_textured_scene_matches_oracle(gpu_ctx, tmp_path, variant):
+    """albedo textures (rtTex2D, repeat + bilinear) on Disney and Disney-glass meshes."""
+    from common import textured_scene
+    hs = textured_scene(tmp_path, 128, 96)
+    spp = 4
+    seeds = M.launch_seeds(spp, 11)
+    default = gpu_ctx.get_option("kernel_variant")
+    try:
+        gpu_ctx.set_option("kernel_variant", variant)
+        gpu_ctx.load(hs)
+        gpu_ctx.accum_clear()
+        st = gpu_ctx.render_counted(seeds)
+        g = gpu_ctx.accum_read()
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(seeds)
+        assert np.array_equal(gpu_ctx.accum_read(), g)
+    finally:
+        gpu_ctx.set_option("kernel_variant", default)
+    o, ost = oracle_scene(hs).render(seeds)
+    e = rmse(g / spp, o / spp)
+    assert e <= RMSE_TIGHT, "paths diverged: rmse %g" % e
+    assert (st.primaryRays, st.bounceRays, st.shadowRays) == (ost.primaryRays, ost.bounceRays, ost.shadowRays)
+    d = hs.to_dict()
+    for m in d["materials"]:
+        m["albedoID"] = 0
+    plain, _ = O.Scene(d).render(seeds)
+    assert rmse(plain / spp, o / spp) > 1e-2          # the textures are visible in the result
+
+
+def test_texture_ids_are_checked(gpu_ctx):
+    import ctypes as C
+    K = M._capi
+    L = K.device_lib()
+    L.moptix_clear_scene(gpu_ctx._h)
+    m = K.Material()
+    m.kind = K.MAT_DISNEY
+    m.disney.albedoID = 1                                # no texture has been added yet
+    assert L.moptix_add_material(gpu_ctx._h, C.byref(m), None) == K.MOPTIX_ERR_INVALID
+    assert "albedoID" in gpu_ctx.last_error()
+    px = np.ones((2, 2, 4), np.float32)
+    tid = C.c_int32()
+    assert L.moptix_add_texture(gpu_ctx._h, px.ctypes.data_as(C.POINTER(C.c_float)), 2, 2, C.byref(tid)) == K.MOPTIX_OK
+    assert tid.value == 1
+    assert L.moptix_add_material(gpu_ctx._h, C.byref(m), None) == K.MOPTIX_OK
+    assert L.moptix_add_texture(gpu_ctx._h, None, 2, 2, None) == K.MOPTIX_ERR_INVALID
+    assert L.moptix_add_texture(gpu_ctx._h, px.ctypes.data_as(C.POINTER(C.c_float)), 0, 2, None) == K.MOPTIX_ERR_INVALID
+    L.moptix_clear_scene(gpu_ctx._h)
