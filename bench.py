@@ -79,12 +79,21 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
     import torch.distributed as dist
-    if world > 1:
+    # MOPTIX_BENCH_FORCE_DIST=1 brings the RCCL group up for a single rank too (exercises init/barrier/all_reduce
+    # on a 1-GPU box); the measured path is unchanged
+    use_dist = world > 1 or os.environ.get("MOPTIX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     dev = torch.device("cuda", local)
+    if use_dist and world == 1:                 # forced single-rank group: the collectives of the N>1 path, once
+        t = torch.arange(12, dtype=torch.float32, device=dev).reshape(4, 3)
+        got = [torch.empty_like(t)]
+        dist.gather(t, got, dst=0)
+        assert torch.equal(got[0], t)
     ctx = M.Context(local)                      # raises when the HIP library / device is missing: no fallback
     hs = M.HostScene(a.scene, a.width, a.height)
     ctx.set_partition(rank, world)
@@ -96,7 +105,7 @@ def main():
     seeds = M.launch_seeds(a.spp)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -106,7 +115,7 @@ def main():
     my_pixels = len(D.tile_pixel_indices(W, H, rank, world))
     my_rays, my_bytes = st.rays, algorithmic_bytes(st, my_pixels)
     tot = torch.tensor([float(my_rays), float(my_bytes)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tot)
     total_rays, total_bytes = float(tot[0].item()), float(tot[1].item())
 
@@ -126,7 +135,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     kms, nlaunch = ctx.kernel_time()
@@ -157,7 +166,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(W, H, a.cpu_launches)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -27,32 +27,45 @@ def max_tile_pixels(width, height, nranks):
     return max(len(tile_pixel_indices(width, height, r, nranks)) for r in range(nranks))
 
 
+_tile_cache = {}
+
+
+def _tile_plan(width, height, rank, nranks, dst, device):
+    """Index tensors and staging buffers of one (frame size, world) pair, built once: the gather sits inside the
+    timed frame, so nothing in it may depend on host work that scales with the pixel count."""
+    import torch
+    key = (width, height, rank, nranks, dst, str(device))
+    plan = _tile_cache.get(key)
+    if plan is None:
+        counts = [len(tile_pixel_indices(width, height, r, nranks)) for r in range(nranks)]
+        nmax = max(counts)
+        mine = torch.from_numpy(tile_pixel_indices(width, height, rank, nranks)).to(device)
+        plan = dict(nmax=nmax, mine=mine, send=torch.zeros((nmax, 3), dtype=torch.float32, device=device))
+        if rank == dst:
+            plan["idx"] = [torch.from_numpy(tile_pixel_indices(width, height, r, nranks)).to(device) for r in range(nranks)]
+            plan["recv"] = [torch.empty((nmax, 3), dtype=torch.float32, device=device) for _ in range(nranks)]
+        _tile_cache[key] = plan
+    return plan
+
+
 def gather_tiles(accum, width, height, rank, nranks, dst=0, group=None):
     """accum: torch tensor [H*W, 3] (or [H, W, 3]) holding this rank's tiles (others untouched).
-    Returns the assembled [H, W, 3] frame on `dst`, None elsewhere."""
+    Returns the assembled [H, W, 3] frame on `dst`, None elsewhere.  One collective: gather to `dst`."""
     import torch
     import torch.distributed as dist
     flat = accum.reshape(-1, 3)
     if nranks == 1:
         return flat.reshape(height, width, 3)
-    idx = [torch.from_numpy(tile_pixel_indices(width, height, r, nranks)).to(flat.device) for r in range(nranks)]
-    nmax = max(len(i) for i in idx)
-    send = torch.zeros((nmax, 3), dtype=flat.dtype, device=flat.device)
-    send[:len(idx[rank])] = flat[idx[rank]]
+    plan = _tile_plan(width, height, rank, nranks, dst, flat.device)
+    send = plan["send"]
+    send[:len(plan["mine"])] = flat[plan["mine"]]
     if rank == dst:
-        recv = [torch.empty_like(send) for _ in range(nranks)]
-        try:
-            dist.gather(send, recv, dst=dst, group=group)
-        except (RuntimeError, NotImplementedError):     # backend without gather: fall back to all_gather
-            dist.all_gather(recv, send, group=group)
+        dist.gather(send, plan["recv"], dst=dst, group=group)
         frame = torch.zeros((height * width, 3), dtype=flat.dtype, device=flat.device)
         for r in range(nranks):
-            frame[idx[r]] = recv[r][:len(idx[r])]
+            frame[plan["idx"][r]] = plan["recv"][r][:len(plan["idx"][r])]
         return frame.reshape(height, width, 3)
-    try:
-        dist.gather(send, None, dst=dst, group=group)
-    except (RuntimeError, NotImplementedError):
-        dist.all_gather([torch.empty_like(send) for _ in range(nranks)], send, group=group)
+    dist.gather(send, None, dst=dst, group=group)
     return None
 
 
