@@ -24,9 +24,10 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_
 
 
 def algorithmic_bytes(st, pixels):
-    """B = 64*N_node + 48*N_tri + 108*N_hit + 72*N_lightLoads + 24*N_accum.
-    N_accum is counted per pixel per launch batch (the per-sample buffer traffic is not claimed)."""
-    return 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * pixels
+    """B = NODE*N_node + 48*N_tri + 108*N_hit + 72*N_lightLoads + 24*N_accum, with NODE = 128:
+    the node record is a four-child 128-byte node (one L2 line) since the binary tree was widened; N_node counts
+    those fetches.  N_accum is counted per pixel per launch batch (the per-sample buffer traffic is not claimed)."""
+    return 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * pixels
 
 
 def cpu_baseline(width, height, n_launches):

@@ -284,7 +284,7 @@ class Context:
 
     def debug_read_accel(self):
         a = self.accel_info()
-        nodes = np.zeros((max(1, a.nNodes), 16), np.uint32)
+        nodes = np.zeros((max(1, a.nNodes), 32), np.uint32)     # Node128 = 32 words
         tris = np.zeros((max(1, a.nTriangles), 12), np.uint32)
         prim = np.zeros(max(1, a.nTriangles), np.int32)
         self._chk(self._L.moptix_debug_read_accel(self._h, nodes.ctypes.data, tris.ctypes.data,

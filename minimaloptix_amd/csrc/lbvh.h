@@ -6,10 +6,11 @@
 namespace pt {
 
 struct LbvhResult {
-  Node64* nodes = nullptr;     // device, nNodes
+  Node128* nodes = nullptr;    // device, nNodes (four-wide)
   Tri48* tris = nullptr;       // device, nTris (sorted / leaf order)
   TriShade* shade = nullptr;   // device, nTris
-  int nTris = 0, nNodes = 0, rootRef = kEmptyRef, depth = 0, leafSize = 0;
+  int nTris = 0, nNodes = 0, rootRef = kEmptyRef, depth = 0, leafSize = 0;   // depth: levels of four-wide nodes
+  int stackBound = 0;          // most entries a traversal stack can hold (3 per level + 1)
   float buildMs = 0.f;
 };
 

@@ -137,42 +137,47 @@ __global__ void k_fit(int n, const int* __restrict__ left, const int* __restrict
   }
 }
 
-// 6a. which Karras nodes survive the collapse
-__global__ void k_kept(int ni, const int* __restrict__ first, const int* __restrict__ last, int leafSize, int* __restrict__ kept) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < ni) kept[i] = (last[i] - first[i] + 1 > leafSize) ? 1 : 0;
-}
-
-// 6b. emit the compacted 64-byte nodes
-__global__ void k_emit(int ni, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ first,
-                       const int* __restrict__ last, const int* __restrict__ kept, const int* __restrict__ newIndex, int leafSize,
-                       const float* __restrict__ leafLo, const float* __restrict__ leafHi, const float* __restrict__ ilo,
-                       const float* __restrict__ ihi, Node64* __restrict__ nodes) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ni || !kept[i]) return;
-  const int l = left[i], r = right[i];
-  const float* l0 = l < 0 ? leafLo + 3 * (~l) : ilo + 3 * l;
-  const float* h0 = l < 0 ? leafHi + 3 * (~l) : ihi + 3 * l;
-  const float* l1 = r < 0 ? leafLo + 3 * (~r) : ilo + 3 * r;
-  const float* h1 = r < 0 ? leafHi + 3 * (~r) : ihi + 3 * r;
-  Node64 nd;
-  nd.a.x = l0[0]; nd.a.y = l0[1]; nd.a.z = l0[2]; nd.a.w = h0[0];
-  nd.b.x = h0[1]; nd.b.y = h0[2]; nd.b.z = l1[0]; nd.b.w = l1[1];
-  nd.c.x = l1[2]; nd.c.y = h1[0]; nd.c.z = h1[1]; nd.c.w = h1[2];
-  nd.c0 = collapsed_ref(l, first, last, newIndex, leafSize);
-  nd.c1 = collapsed_ref(r, first, last, newIndex, leafSize);
-  nd.pad0 = 0; nd.pad1 = 0;
-  nodes[newIndex[i]] = nd;
-}
-
-// 7. depth of the emitted tree = longest chain of kept ancestors
-__global__ void k_depth(int ni, const int* __restrict__ kept, const int* __restrict__ parentI, int* depthOut) {
+// 6a/7a. which Karras nodes become four-wide nodes, and on which level (0 = none)
+__global__ void k_kept(int ni, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ first,
+                       const int* __restrict__ last, const int* __restrict__ parentI, int leafSize,
+                       const float* __restrict__ ilo, const float* __restrict__ ihi, int* __restrict__ kept, int* depthOut) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int d = 0;
-  if (i < ni && kept[i]) { int p = i; while (p >= 0) { d++; p = parentI[p]; } }
+  if (i < ni) { d = wide_level(i, left, right, first, last, parentI, leafSize, ilo, ihi); kept[i] = d > 0 ? 1 : 0; }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) d = max(d, __shfl_xor(d, o));
   if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(depthOut, d);
+}
+
+// 7b. emit the compacted 128-byte nodes
+__global__ void k_emit(int ni, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ first,
+                       const int* __restrict__ last, const int* __restrict__ kept, const int* __restrict__ newIndex, int leafSize,
+                       const float* __restrict__ leafLo, const float* __restrict__ leafHi, const float* __restrict__ ilo,
+                       const float* __restrict__ ihi, Node128* __restrict__ nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ni || !kept[i]) return;
+  int ch[4], opened[2];
+  const int n = wide_children(i, left, right, first, last, leafSize, ilo, ihi, ch, opened);
+  float lo[3][4], hi[3][4];
+  Node128 nd;
+  for (int k = 0; k < 4; k++) {
+    if (k < n) {
+      const int c = ch[k];
+      const float* l = c < 0 ? leafLo + 3 * (size_t)(~c) : ilo + 3 * (size_t)c;
+      const float* h = c < 0 ? leafHi + 3 * (size_t)(~c) : ihi + 3 * (size_t)c;
+      for (int a = 0; a < 3; a++) { lo[a][k] = l[a]; hi[a][k] = h[a]; }
+      nd.ref[k] = collapsed_ref(c, first, last, newIndex, leafSize);
+    } else {
+      for (int a = 0; a < 3; a++) { lo[a][k] = 0.f; hi[a][k] = 0.f; }
+      nd.ref[k] = kEmptyRef;
+    }
+  }
+  nd.lox = mk4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]); nd.loy = mk4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+  nd.loz = mk4(lo[2][0], lo[2][1], lo[2][2], lo[2][3]);
+  nd.hix = mk4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]); nd.hiy = mk4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]);
+  nd.hiz = mk4(hi[2][0], hi[2][1], hi[2][2], hi[2][3]);
+  nd.count = n; nd.pad[0] = 0; nd.pad[1] = 0; nd.pad[2] = 0;
+  nodes[newIndex[i]] = nd;
 }
 
 template <class T> hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, sizeof(T) * (n ? n : 1)); }
@@ -237,7 +242,7 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
     LB_CHECK(hipMemsetAsync(dDepth, 0, sizeof(int), stream));
     k_karras<<<grid_for(ni), kBlock, 0, stream>>>(n, keysSorted, left, right, first, last, parentI, parentL);
     k_fit<<<grid_for(n), kBlock, 0, stream>>>(n, left, right, parentI, parentL, leafLo, leafHi, ilo, ihi, arrivals);
-    k_kept<<<grid_for(ni), kBlock, 0, stream>>>(ni, first, last, leafSize, kept);
+    k_kept<<<grid_for(ni), kBlock, 0, stream>>>(ni, left, right, first, last, parentI, leafSize, ilo, ihi, kept, dDepth);
     LB_CHECK(rocprim::exclusive_scan(tmp, tmpScan, kept, newIndex, 0, (size_t)ni, rocprim::plus<int>(), stream));
     LB_CHECK(hipMemcpyAsync(&hostCount[0], newIndex + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
     LB_CHECK(hipMemcpyAsync(&hostCount[1], kept + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -245,7 +250,6 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
     out->nNodes = hostCount[0] + hostCount[1];
     LB_CHECK(dmalloc(&out->nodes, (size_t)out->nNodes));
     k_emit<<<grid_for(ni), kBlock, 0, stream>>>(ni, left, right, first, last, kept, newIndex, leafSize, leafLo, leafHi, ilo, ihi, out->nodes);
-    k_depth<<<grid_for(ni), kBlock, 0, stream>>>(ni, kept, parentI, dDepth);
     LB_CHECK(hipMemcpyAsync(&out->depth, dDepth, sizeof(int), hipMemcpyDeviceToHost, stream));
     out->rootRef = 0;
   }
@@ -253,6 +257,7 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
   LB_CHECK(hipStreamSynchronize(stream));
   LB_CHECK(hipGetLastError());
   (void)hipEventElapsedTime(&out->buildMs, e0, e1);
+  out->stackBound = wide_stack_bound(out->depth);
 
 done:
   for (void* p : { (void*)lo, (void*)hi, (void*)leafLo, (void*)leafHi, (void*)ilo, (void*)ihi, (void*)keys, (void*)keysSorted,

@@ -129,7 +129,7 @@ int check_ready(moptix_context c) {
 }
 
 int read_stats(moptix_context c, moptix_stats* stats) {
-  unsigned long long h[24];
+  unsigned long long h[40];
   HIPCHK(c, hipMemcpy(h, c->dCounters.p, sizeof(h), hipMemcpyDeviceToHost), "read counters");
   stats->samples = h[0]; stats->primaryRays = h[1]; stats->bounceRays = h[2]; stats->shadowRays = h[3];
   stats->nodeFetches = h[4]; stats->triTests = h[5]; stats->closestHits = h[6]; stats->lightLoads = h[7];
@@ -141,6 +141,9 @@ int read_stats(moptix_context c, moptix_stats* stats) {
     fprintf(stderr, "[moptix] wave time: batch %.1f%% refill %.1f%% node %.1f%% leaf %.1f%% finish %.1f%% (steps %llu, cycles/wave %.3g)\n",
             100 * h[16] / tt, 100 * h[17] / tt, 100 * h[18] / tt, 100 * h[19] / tt, 100 * h[20] / tt, h[9], tt);
     fprintf(stderr, "[moptix] idle spins %llu\n", h[14]);
+    if (h[32]) fprintf(stderr, "[moptix] swap detail: local %.1f%% lock-wait %.1f%% txn %.1f%% idle %.1f%% | batch detail: load %.1f%% run %.1f%% store %.1f%% | "
+                       "iterations %llu transactions %llu (cycles/iter %.0f)\n", 100 * h[24] / tt, 100 * h[25] / tt, 100 * h[26] / tt, 100 * h[27] / tt,
+                       100 * h[28] / tt, 100 * h[29] / tt, 100 * h[30] / tt, h[32], h[31], tt / (double)h[32]);
     if (h[22]) fprintf(stderr, "[moptix] node steps %llu (%.1f lanes avg), leaf passes %llu (%.1f lanes avg)\n", h[9] - h[22],
             (double)(h[10] - h[23]) / (double)(h[9] - h[22]), h[22], (double)h[23] / (double)h[22]);
   }
@@ -181,7 +184,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   const bool useQueue = (c->optVariant == 2 || c->optVariant == 3) && hasTris;
   a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;
   if (useQueue) {
-    a.ovfDepth = std::max(0, c->bvh.depth - queuekernel_lds_stack_entries() + 1);
+    a.ovfDepth = std::max(0, c->bvh.stackBound - queuekernel_lds_stack_entries() + 1);
     if (a.ovfDepth > 0) {
       HIPCHK(c, c->dOverflow.ensure(queuekernel_overflow_ints(nBlocks, a.ovfDepth)), "alloc stack overflow area");
       a.stackOverflow = c->dOverflow.p;
@@ -190,8 +193,8 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     a.poolCold = c->dPoolCold.p;
   } else {
     const int ldsStack = usePool ? poolkernel_lds_stack_entries() : megakernel_lds_stack_entries();
-    if (c->bvh.depth > ldsStack) {
-      const size_t need = (size_t)(c->bvh.depth - ldsStack + 1) * nBlocks * 256;
+    if (c->bvh.stackBound > ldsStack) {
+      const size_t need = (size_t)(c->bvh.stackBound - ldsStack + 1) * nBlocks * 256;
       HIPCHK(c, c->dOverflow.ensure(need), "alloc stack overflow area");
       a.stackOverflow = c->dOverflow.p;
     }
@@ -205,8 +208,8 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   HIPCHK(c, c->dWork.ensure(2), "alloc work counter");   // [0] work counter, [1] watchdog flag
   a.workCounter = c->dWork.p;
   if (counted) {
-    HIPCHK(c, c->dCounters.ensure(24), "alloc counters");
-    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * 24, c->stream), "zero counters");
+    HIPCHK(c, c->dCounters.ensure(40), "alloc counters");
+    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * 40, c->stream), "zero counters");
     a.counters = c->dCounters.p;
   }
   std::vector<int> hs(seeds, seeds + nSeeds);
@@ -456,7 +459,7 @@ int moptix_get_accel_info(moptix_context c, moptix_accel_info* out) {
   memset(out, 0, sizeof(*out));
   out->nTriangles = (uint32_t)c->bvh.nTris; out->nNodes = (uint32_t)c->bvh.nNodes; out->maxLeafSize = (uint32_t)c->bvh.leafSize;
   out->treeDepth = (uint32_t)c->bvh.depth; out->buildMs = c->bvh.buildMs;
-  out->nodeBytes = (uint64_t)c->bvh.nNodes * sizeof(Node64); out->triBytes = (uint64_t)c->bvh.nTris * sizeof(Tri48);
+  out->nodeBytes = (uint64_t)c->bvh.nNodes * sizeof(Node128); out->triBytes = (uint64_t)c->bvh.nTris * sizeof(Tri48);
   return MOPTIX_OK;
 }
 
@@ -604,7 +607,7 @@ int moptix_debug_read_accel(moptix_context c, void* nodes, void* tris, int32_t* 
   if (!c) return MOPTIX_ERR_INVALID;
   if (!c->accelBuilt) return fail(c, MOPTIX_ERR_STATE, "no acceleration structure");
   HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
-  if (nodes && c->bvh.nNodes > 0) HIPCHK(c, hipMemcpy(nodes, c->bvh.nodes, sizeof(Node64) * c->bvh.nNodes, hipMemcpyDeviceToHost), "read nodes");
+  if (nodes && c->bvh.nNodes > 0) HIPCHK(c, hipMemcpy(nodes, c->bvh.nodes, sizeof(Node128) * c->bvh.nNodes, hipMemcpyDeviceToHost), "read nodes");
   if ((tris || triPrimIds) && c->bvh.nTris > 0) {
     std::vector<Tri48> h(c->bvh.nTris);
     HIPCHK(c, hipMemcpy(h.data(), c->bvh.tris, sizeof(Tri48) * c->bvh.nTris, hipMemcpyDeviceToHost), "read tris");
@@ -624,9 +627,9 @@ int moptix_debug_trace(moptix_context c, const float* rays, int32_t n, float* ou
   HIPCHK(c, hipMalloc((void**)&dR, sizeof(float) * 8 * (size_t)n), "alloc rays");
   HIPCHK(c, hipMalloc((void**)&dT, sizeof(float) * (size_t)n), "alloc t");
   HIPCHK(c, hipMalloc((void**)&dP, sizeof(int) * (size_t)n), "alloc prim");
-  if (c->bvh.depth > megakernel_lds_stack_entries()) {
+  if (c->bvh.stackBound > megakernel_lds_stack_entries()) {
     const size_t threads = ((size_t)n + 255) / 256 * 256;
-    HIPCHK(c, hipMalloc((void**)&dOvf, sizeof(int) * threads * (size_t)(c->bvh.depth - megakernel_lds_stack_entries() + 1)), "alloc overflow");
+    HIPCHK(c, hipMalloc((void**)&dOvf, sizeof(int) * threads * (size_t)(c->bvh.stackBound - megakernel_lds_stack_entries() + 1)), "alloc overflow");
   }
   SceneView v; fill_view(c, v);
   hipError_t e = hipMemcpyAsync(dR, rays, sizeof(float) * 8 * (size_t)n, hipMemcpyHostToDevice, c->stream);

@@ -52,8 +52,10 @@ PT_HD v3 cosine_sample_hemisphere(float u1, float u2) {
   const float r = __builtin_sqrtf(u1);
   const float phi = (2.0f * kPi) * u2;
   v3 p;
-  p.x = r * cos_ac(phi);
-  p.y = r * sin_ac(phi);
+  float sinPhi, cosPhi;
+  sincos_ac(phi, sinPhi, cosPhi);
+  p.x = r * cosPhi;
+  p.y = r * sinPhi;
   p.z = __builtin_sqrtf(fmaxf_(0.0f, 1.0f - p.x * p.x - p.y * p.y));
   return p;
 }
@@ -73,8 +75,8 @@ PT_HD_BRDF void disney_sample(uint32_t& seed, const DevMaterial& m, v3 N, v3 V, 
     float random = rnd(seed);
     float cosTheta = __builtin_sqrtf((1.f - random) / (1.0f + (a * a - 1.f) * random));
     float sinTheta = __builtin_sqrtf(1.0f - (cosTheta * cosTheta));
-    float sinPhi = sin_ac(phi);
-    float cosPhi = cos_ac(phi);
+    float sinPhi, cosPhi;
+    sincos_ac(phi, sinPhi, cosPhi);
     v3 h = mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
     h = onb_inverse(onb, h);
     L = normalize(h * (2.0f * dot(V, h)) - V);

@@ -8,8 +8,9 @@
 //   4. Karras 2012 radix tree over the sorted keys (one thread per internal node)
 //   5. bottom-up box fit with one atomic arrival counter per node
 //   6. collapse: every subtree with <= leafSize triangles becomes one leaf
-//      (first,count) in sorted order; surviving nodes are compacted and emitted as
-//      64-byte two-child nodes
+//      (first,count) in sorted order
+//   7. widening: a surviving node absorbs the surviving descendants with the largest surface area until it
+//      has four children; the resulting nodes are compacted and emitted as 128-byte four-child nodes
 //
 // All steps are pure functions of the key order (min/max unions are exact), so the tree is
 // bit-reproducible; tests/hostsim runs the same functions sequentially on the host and the
@@ -103,5 +104,61 @@ PT_HD int collapsed_ref(int child, const int* first, const int* last, const int*
   if (count <= leafSize) return make_leaf_ref(first[child], count);
   return newIndex[child];
 }
+
+// ---- widening (binary -> four-wide) ----
+// A Karras node survives the collapse when its range holds more than leafSize triangles; every ancestor of a
+// surviving node survives too.  A wide node starts from a surviving node's two children and, while it has
+// fewer than four, opens the surviving child with the largest surface area (replacing it by its two children,
+// order kept).  Opened nodes disappear; the surviving children that are left become wide nodes themselves.
+PT_HD bool karras_kept(int c, const int* first, const int* last, int leafSize) {
+  return c >= 0 && last[c] - first[c] + 1 > leafSize;
+}
+PT_HD float half_area(const float* lo, const float* hi) {
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  return (dx * dy + dy * dz) + dz * dx;
+}
+// Karras children (>=0 internal, <0 leaf) of wide node r, left to right; opened[] receives the absorbed nodes
+PT_HD int wide_children(int r, const int* left, const int* right, const int* first, const int* last, int leafSize,
+                        const float* ilo, const float* ihi, int out[4], int opened[2]) {
+  int n = 2, nOpen = 0;
+  out[0] = left[r]; out[1] = right[r]; opened[0] = -1; opened[1] = -1;
+  while (n < 4) {
+    int best = -1; float bestA = -1.0f;
+    for (int k = 0; k < n; k++) {
+      const int c = out[k];
+      if (!karras_kept(c, first, last, leafSize)) continue;
+      const float A = half_area(ilo + 3 * (size_t)c, ihi + 3 * (size_t)c);
+      if (A > bestA) { bestA = A; best = k; }          // ties: the leftmost
+    }
+    if (best < 0) break;
+    const int c = out[best];
+    opened[nOpen++] = c;
+    for (int k = n; k > best + 1; k--) out[k] = out[k - 1];
+    out[best] = left[c]; out[best + 1] = right[c];
+    n++;
+  }
+  return n;
+}
+// Level (1 = root) of Karras node i in the wide tree, or 0 when i does not survive or is absorbed by a wide
+// node above it.  Decided by replaying the choices along the path from the root: O(depth) work per node, no
+// communication between nodes, same answer on every run.  Keys are 64 bits, so a path has at most 64 nodes.
+PT_HD int wide_level(int i, const int* left, const int* right, const int* first, const int* last, const int* parentI,
+                     int leafSize, const float* ilo, const float* ihi) {
+  if (!karras_kept(i, first, last, leafSize)) return 0;
+  int path[66]; int np = 0;
+  for (int p = i; p >= 0 && np < 66; p = parentI[p]) path[np++] = p;
+  int k = np - 1, level = 1;
+  for (;;) {
+    const int cur = path[k];
+    if (cur == i) return level;
+    int ch[4], op[2];
+    wide_children(cur, left, right, first, last, leafSize, ilo, ihi, ch, op);
+    k--;
+    while (path[k] == op[0] || path[k] == op[1]) { if (path[k] == i) return 0; k--; }
+    level++;
+  }
+}
+// a traversal stack never holds more than 3 entries per level of the wide tree
+PT_HD int wide_stack_bound(int wideDepth) { return 3 * wideDepth + 1; }
 
 }  // namespace pt

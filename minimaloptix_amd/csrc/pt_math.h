@@ -39,6 +39,7 @@ struct alignas(16) v4 { float x, y, z, w; };
 
 PT_HD v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_HD v3 splat3(float s) { return mk3(s, s, s); }
+PT_HD v4 mk4(float x, float y, float z, float w) { v4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 PT_HD v3 xyz(const v4& a) { return mk3(a.x, a.y, a.z); }
 PT_HD v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 PT_HD v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -63,8 +64,24 @@ PT_HD float fminf_(float a, float b) { return __builtin_fminf(a, b); }
 PT_HD float fmaxf_(float a, float b) { return __builtin_fmaxf(a, b); }
 PT_HD float clampf(float x, float lo, float hi) { return fmaxf_(lo, fminf_(x, hi)); }
 PT_HD float sqr(float x) { return x * x; }
-PT_HD float sin_ac(float x) { return (float)sin((double)x); }     // AC5
-PT_HD float cos_ac(float x) { return (float)cos((double)x); }
+// AC5: sin and cos as ONE specified binary32 algorithm (both sides of the parity contract evaluate exactly these
+// operations): quadrant q = floor(x*2/pi + 1/2), three-step Cody-Waite reduction r = x - q*pi/2 with fma, degree-7 /
+// degree-8 polynomials on |r| <= pi/4 (coefficients of the classic single-precision kernels), quadrant fix-up.
+// Absolute error < 2e-7 for |x| < 100; the path tracer only calls it with x in [0, 2 pi].
+PT_HD void sincos_ac(float x, float& s, float& c) {
+  const float qf = __builtin_floorf(fma_(x, 0.636619772f, 0.5f));
+  float r = fma_(qf, -1.5703125f, x);
+  r = fma_(qf, -4.837512969970703125e-4f, r);
+  r = fma_(qf, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float sp = fma_(fma_(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  const float cp = fma_(fma_(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  const float sr = fma_(sp * z, r, r);
+  const float cr = fma_(cp * z, z, fma_(-0.5f, z, 1.0f));
+  const int q = (int)qf & 3;
+  s = (q == 0) ? sr : (q == 1) ? cr : (q == 2) ? -sr : -cr;
+  c = (q == 0) ? cr : (q == 1) ? -sr : (q == 2) ? -cr : sr;
+}
 
 PT_HD int32_t f2i(float f) { return __builtin_bit_cast(int32_t, f); }
 PT_HD float i2f(int32_t i) { return __builtin_bit_cast(float, i); }

@@ -130,24 +130,37 @@ PT_HD void trav_pop(Trav& tv, Stack& st) {
   else { tv.sp--; tv.node = st.load(tv.sp); }
 }
 
-// One two-child node (one 64-byte fetch) for a lane with tv.node >= 0.
+// One four-child node (one 128-byte line) for a lane with tv.node >= 0: the children the ray enters are
+// visited nearest first (a 5-exchange sorting network on (entry distance, ref)); the order affects only the
+// amount of work, never the result (equal-t rule D5 is order independent).
+PT_HD void sort2(float& ta, int& ra, float& tb, int& rb) {
+  const bool sw = tb < ta;
+  const float t0 = sw ? tb : ta, t1 = sw ? ta : tb;
+  const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+  ta = t0; tb = t1; ra = r0; rb = r1;
+}
 template <bool CNT, class Stack>
 PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
   {
-    const Node64* np = sc.nodes + tv.node;
-    const v4 a = np->a, b = np->b, c = np->c;
-    const int c0 = np->c0, c1 = np->c1;
+    const Node128* np = sc.nodes + tv.node;
+    const v4 lox = np->lox, loy = np->loy, loz = np->loz, hix = np->hix, hiy = np->hiy, hiz = np->hiz;
+    int r0 = np->ref[0], r1 = np->ref[1], r2 = np->ref[2], r3 = np->ref[3];
     cnt<CNT>(ct.nodeFetches);
-    float tn0, tn1;
-    const bool h0 = slab(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), ps.o, tv.inv, ps.tmin, tv.tbest, tn0);
-    const bool h1 = slab(mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), ps.o, tv.inv, ps.tmin, tv.tbest, tn1);
-    if (h0 & h1) {
-      const bool firstIs0 = tn0 <= tn1;
-      st.store(tv.sp, firstIs0 ? c1 : c0); tv.sp++;
-      tv.node = firstIs0 ? c0 : c1;
-    } else if (h0) tv.node = c0;
-    else if (h1) tv.node = c1;
-    else trav_pop(tv, st);
+    const float kFar = 3.0e38f;
+    float t0, t1, t2, t3;
+    if (!slab(mk3(lox.x, loy.x, loz.x), mk3(hix.x, hiy.x, hiz.x), ps.o, tv.inv, ps.tmin, tv.tbest, t0)) t0 = kFar;
+    if (!slab(mk3(lox.y, loy.y, loz.y), mk3(hix.y, hiy.y, hiz.y), ps.o, tv.inv, ps.tmin, tv.tbest, t1)) t1 = kFar;
+    if (!slab(mk3(lox.z, loy.z, loz.z), mk3(hix.z, hiy.z, hiz.z), ps.o, tv.inv, ps.tmin, tv.tbest, t2) || r2 == kEmptyRef) t2 = kFar;
+    if (!slab(mk3(lox.w, loy.w, loz.w), mk3(hix.w, hiy.w, hiz.w), ps.o, tv.inv, ps.tmin, tv.tbest, t3) || r3 == kEmptyRef) t3 = kFar;
+    sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2); sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
+    if (t0 < kFar) {
+      if (t3 < kFar) { st.store(tv.sp, r3); tv.sp++; }
+      if (t2 < kFar) { st.store(tv.sp, r2); tv.sp++; }
+      if (t1 < kFar) { st.store(tv.sp, r1); tv.sp++; }
+      tv.node = r0;
+    } else {
+      trav_pop(tv, st);
+    }
   }
 }
 

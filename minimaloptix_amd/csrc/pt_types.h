@@ -2,7 +2,7 @@
 //
 // Everything the traversal loop touches is 16-byte aligned and sized so that one
 // record = a whole number of dwordx4 loads:
-//   Node64  : 64 B  two-child BVH node (both child boxes + both child refs)  -> 4 x dwordx4
+//   Node128 : 128 B four-child BVH node (one L2 cache line: 4 child boxes SoA + 4 child refs) -> 7 x dwordx4
 //   Tri48   : 48 B  triangle record p0,e0,e1 (+ material / primitive id in .w) -> 3 x dwordx4
 //   TriShade: 48 B  the three vertex normals, fetched once per closest hit
 // Analytic primitives (spheres/quads, incl. light geometry) live in short brute-force
@@ -20,14 +20,16 @@ PT_HD int leaf_count(int ref) { return ((~ref) & 7) + 1; }
 constexpr int kTravDone = 0x7fffffff;   // traversal finished sentinel in Trav::node
 constexpr int kEmptyRef = 0x7ffffffe;   // "no triangles" root
 
-struct alignas(64) Node64 {
-  v4 a;   // lo0.x lo0.y lo0.z hi0.x
-  v4 b;   // hi0.y hi0.z lo1.x lo1.y
-  v4 c;   // lo1.z hi1.x hi1.y hi1.z
-  int c0, c1;      // child references
-  int pad0, pad1;
+// Four-wide node: every second level of the binary radix tree is folded into its parent, so a ray makes half
+// as many dependent fetches, each of exactly one 128-byte L2 line.  Unused child slots hold kEmptyRef.
+struct alignas(128) Node128 {
+  v4 lox, loy, loz;     // lower corners of children 0..3 (component k of each = child k)
+  v4 hix, hiy, hiz;     // upper corners
+  int ref[4];           // child references (node index, leaf ref or kEmptyRef)
+  int count;            // children in use (2..4)
+  int pad[3];
 };
-static_assert(sizeof(Node64) == 64, "Node64 must be 64 bytes");
+static_assert(sizeof(Node128) == 128, "Node128 must be 128 bytes");
 
 struct alignas(16) Tri48 {
   v3 p0; int mat;        // material id of the face
@@ -113,7 +115,7 @@ struct SceneView {
   int nMaterials; const DevMaterial* mats;
   int anyDisneyAnalytic;          // any sphere/quad carries a Disney material (shadow any-hit applies)
   int nTris; int rootRef;         // rootRef: node index, leaf ref or kEmptyRef
-  const Node64* nodes; const Tri48* tris; const TriShade* triShade;
+  const Node128* nodes; const Tri48* tris; const TriShade* triShade;
   const TriUV* triUV;             // per face in upload order, or nullptr (no mesh has texcoords)
   int nTextures; const DevTexture* textures;
 };

@@ -151,6 +151,11 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
   SlotCold* cold = reinterpret_cast<SlotCold*>(a.poolCold) + (size_t)gpool * NS;
   int* ovfBase = a.stackOverflow ? a.stackOverflow + (size_t)gpool * NS * a.ovfDepth : nullptr;
 
+  // sub-phase clocks of the counting build
+  unsigned long long tLocal = 0, tLock = 0, tTxn = 0, tIdle = 0, tBLoad = 0, tBRun = 0, tBStore = 0, nTxn = 0, nIter = 0;
+  unsigned long long tSub = 0;
+#define PT_SUB0() do { if (CNT) tSub = __builtin_amdgcn_s_memtime(); } while (0)
+#define PT_SUB(acc) do { if (CNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tSub; tSub = now_; } } while (0)
   // queue bookkeeping: registers (wave-uniform); with SHARED they mirror LDS inside a transaction
   int qHead[kNumQ] = { 0, 0, 0, 0 }, qCount[kNumQ] = { 0, 0, 0, 0 };
   int nDone = 0;
@@ -174,6 +179,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     if constexpr (SHARED) {
       if (lane == 0) { while (atomicCAS(&W.lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1); }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (CNT) { (void)__builtin_amdgcn_readfirstlane(W.lock); PT_SUB(tLock); nTxn++; }
       for (int q = 0; q < kNumQ; q++) {
         qHead[q] = __builtin_amdgcn_readfirstlane(W.qHead[q]);
         qCount[q] = __builtin_amdgcn_readfirstlane(W.qCount[q]);
@@ -274,13 +280,17 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       }
       pendDest = route(tv.node, ps.kind, tv.bestPrim);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // slot records in HBM are re-read by other lanes / waves
+    // Slot records in HBM are re-read by other lanes / waves.  With a shared pool a slot only reaches another wave
+    // through a queue transaction, whose release fence (txn_end) covers these stores: no wait here, the store
+    // latency overlaps with the bookkeeping that follows.
+    if constexpr (!SHARED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   };
 
   // ---- shading / regeneration batch: run the path state machine for the popped slots ----
   auto run_batch = [&](int slot, bool shadeBatch) {
     const bool have = slot >= 0;
     if (CNT) { batches++; batchLanes += (uint32_t)__popcll(__ballot(have)); }
+    PT_SUB0();
     pendSlot = slot; pendDest = DEST_NONE;
     PathState ps; Trav res;
     ps.mode = M_DONE; ps.kind = RK_RADIANCE;
@@ -298,6 +308,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       res.beta = c.c0; res.gamma = c.c1; res.att = mk3(c.c0, c.c1, c.c2);
       if (ps.mode == M_TRACE) ps.mode = M_RESULT;
     }
+    if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBLoad); }
     for (;;) {
       if (have && ps.mode == M_NEW_SAMPLE) { store_sample(a, ps.item, ps.accum); ps.mode = M_NEW_PIXEL; }
       const bool run = have && ps.mode != M_TRACE && ps.mode != M_DONE && !(shadeBatch && ps.mode == M_NEW_PIXEL);
@@ -315,6 +326,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         }
       }
     }
+    if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBRun); }
     if (have) {
       SlotCold c;
       c.mode = ps.mode; c.pixel = ps.pixel; c.item = ps.item; c.depth = ps.depth; c.seed = ps.seed;
@@ -341,7 +353,8 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         pendDest = (ps.mode == M_NEW_PIXEL) ? Q_GEN : DEST_DONE;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if constexpr (!SHARED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    PT_SUB(tBStore);
   };
 
   // per-wave private structures: the node-ready ring (slots produced by this wave's own passes
@@ -372,6 +385,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
   unsigned int guard = 0;
   for (;;) {
     if (++guard > (1u << 27)) { if (lane == 0) atomicOr(a.workCounter + 1, 1); break; }   // bounded: never hang the GPU
+    PT_SUB0(); if (CNT) nIter++;
     // ---- local bookkeeping (no lock): results of the last pass, swap, refill ----
     if (__ballot(pendDest != DEST_NONE) != 0ull) { local_push(pendDest, pendSlot); pendDest = DEST_NONE; }
     {
@@ -408,6 +422,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     int mySlot = -1;
     if (starving || obCount[0] >= 32 || obCount[1] >= 32 || obCount[2] >= 32) {
       // =========================== queue transaction ===========================
+      PT_SUB(tLocal);
       txn_begin();
       for (int d = 0; d < 3; d++) {
         const int q = Q_LEAF + d;
@@ -428,11 +443,12 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       }
       if (pass >= 0 && pass <= 2) mySlot = q_pop(pass == 0 ? Q_LEAF : (pass == 1 ? Q_SHADE : Q_GEN), true);
       txn_end();
+      PT_SUB(tTxn);
       // =========================================================================
-    }
+    } else PT_SUB(tLocal);
     PT_STAMP(tSwap);
     if (pass == 4) break;
-    if (pass == 3) { if (CNT) idleSpins++; __builtin_amdgcn_s_sleep(32); continue; }
+    if (pass == 3) { if (CNT) idleSpins++; __builtin_amdgcn_s_sleep(32); PT_SUB(tIdle); PT_STAMP(tSwap); continue; }
     if (pass == 0) { leaf_pass(mySlot); PT_STAMP(tLeaf); continue; }
     if (pass > 0) { run_batch(mySlot, pass == 1); PT_STAMP(tBatch); continue; }
 
@@ -466,6 +482,8 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       atomicAdd(&c[16], tBatch); atomicAdd(&c[17], tSwap); atomicAdd(&c[18], tNode); atomicAdd(&c[19], tLeaf);
       atomicAdd(&c[21], __builtin_amdgcn_s_memtime() - tStart);
       atomicAdd(&c[22], (unsigned long long)leafPasses); atomicAdd(&c[23], (unsigned long long)leafLanes);
+      atomicAdd(&c[24], tLocal); atomicAdd(&c[25], tLock); atomicAdd(&c[26], tTxn); atomicAdd(&c[27], tIdle);
+      atomicAdd(&c[28], tBLoad); atomicAdd(&c[29], tBRun); atomicAdd(&c[30], tBStore); atomicAdd(&c[31], nTxn); atomicAdd(&c[32], nIter);
     }
   }
 }

@@ -47,9 +47,26 @@ static inline float lerpf(float a, float b, float t) { return a + t * (b - a); }
 static inline f3 lerp3(f3 a, f3 b, float t) { return add3(a, scl3(sub3(b, a), t)); }
 static inline float clampf(float x, float lo, float hi) { return fmaxf(lo, fminf(x, hi)); }
 static inline float sqr(float x) { return x * x; }                                          /* utils_device.h:145 */
-/* AC5 */
-static inline float sin_ac(float x) { return (float)sin((double)x); }
-static inline float cos_ac(float x) { return (float)cos((double)x); }
+/* AC5: sin and cos by the contract's binary32 algorithm (quadrant, 3-step Cody-Waite reduction with fma,
+ * degree-7/8 kernels on |r| <= pi/4, quadrant fix-up); written out here independently of the kernels */
+static inline void sincos_ac(float x, float* s, float* c) {
+  const float qf = floorf(fmaf(x, 0.636619772f, 0.5f));
+  float r = fmaf(qf, -1.5703125f, x);
+  r = fmaf(qf, -4.837512969970703125e-4f, r);
+  r = fmaf(qf, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float sp = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  const float cp = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  const float sr = fmaf(sp * z, r, r);
+  const float cr = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
+  switch ((int)qf & 3) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+  }
+}
+void orc_sincos(float x, float* s, float* c) { sincos_ac(x, s, c); }
 
 #define ORC_PI 3.14159265358979323846f  /* M_PIf */
 #define ORC_RT_DEFAULT_MAX 1e27f
@@ -257,8 +274,10 @@ static f3 cosine_sample_hemisphere(float u1, float u2) {
   const float r = sqrtf(u1);
   const float phi = (2.0f * ORC_PI) * u2;
   f3 p;
-  p.x = r * cos_ac(phi);
-  p.y = r * sin_ac(phi);
+  float sinPhi, cosPhi;
+  sincos_ac(phi, &sinPhi, &cosPhi);
+  p.x = r * cosPhi;
+  p.y = r * sinPhi;
   p.z = sqrtf(fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
   return p;
 }
@@ -278,8 +297,8 @@ static void disney_sample(int32_t* seed, const OrcMaterial* m, f3 N, f3 V, f3* L
     float random = orc_rand(seed);
     float cosTheta = sqrtf((1.f - random) / (1.0f + (a * a - 1.f) * random));
     float sinTheta = sqrtf(1.0f - (cosTheta * cosTheta));
-    float sinPhi = sin_ac(phi);
-    float cosPhi = cos_ac(phi);
+    float sinPhi, cosPhi;
+    sincos_ac(phi, &sinPhi, &cosPhi);
     f3 h = mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
     h = onb_inverse(&onb, h);
     *L = norm3(sub3(scl3(h, 2.0f * dot3(V, h)), V));

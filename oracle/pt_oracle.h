@@ -25,7 +25,8 @@
  *   AC3 length(v)=sqrtf(dot(v,v)); normalize(v)=v*(1.0f/sqrtf(dot(v,v))); v/s = v*(1.0f/s)
  *   AC4 every other C operator is one IEEE binary32 operation, in source order
  *       (compile with -ffp-contract=off)
- *   AC5 sinf/cosf(x) := (float)sin((double)x), (float)cos((double)x)
+ *   AC5 sinf/cosf(x) := one specified binary32 algorithm (quadrant + 3-step Cody-Waite reduction with fma +
+ *       degree-7/8 kernels; see sincos_ac), absolute error < 2e-7 on [0, 2 pi]
  *   AC6 logf of per-material constants is evaluated with the host libm; x^2.2 (srgb2lin) is
  *       (float)pow((double)x, (double)2.2f) -- it is per-hit for textured materials
  *   AC7 point on ray  p = fmaf(t, d, o) per component
@@ -149,6 +150,7 @@ int   orc_intersect_triangle(const float o[3], const float d[3], float tmin, flo
 void  orc_move_sphere(float center[3], float radius, float velocity[3], float time);
 /* rtTex2D<float4> restated (SURVEY A1 / CUDA linear filtering with 8-bit interpolation weights) */
 void  orc_tex2d(const OrcTexture* t, float u, float v, float out[4]);
+void  orc_sincos(float x, float* s, float* c);                /* AC5 */
 int   orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -93,7 +93,7 @@ def hostsim_render(hs, seeds, leaf_size=4, accum=None):
 def hostsim_bvh(hs, leaf_size=4):
     s, keep = _hostsim_scene(hs)
     nf = max(1, s.nFaces)
-    nodes = np.zeros((nf, 16), np.uint32); tris = np.zeros((nf, 12), np.uint32); prim = np.zeros(nf, np.int32)
+    nodes = np.zeros((nf, 32), np.uint32); tris = np.zeros((nf, 12), np.uint32); prim = np.zeros(nf, np.int32)
     out = HostsimBvhOut()
     out.nodes, out.tris, out.triPrim = nodes.ctypes.data, tris.ctypes.data, prim.ctypes.data_as(C.POINTER(C.c_int32))
     rc = hostsim_lib().hostsim_build_bvh(C.byref(s), leaf_size, C.byref(out))

@@ -35,7 +35,7 @@ struct hostsim_scene {
   const float* const* texels;                  // nTextures pointers to 4*w*h floats
 };
 
-struct hostsim_bvh_out {      // caller-allocated: nodes >= max(1,nFaces-1)*64 B, tris nFaces*48 B
+struct hostsim_bvh_out {      // caller-allocated: nodes >= max(1,nFaces-1)*128 B, tris nFaces*48 B
   void* nodes; void* tris; int32_t* triPrim;
   int32_t nNodes, rootRef, depth;
 };
@@ -45,11 +45,11 @@ struct hostsim_bvh_out {      // caller-allocated: nodes >= max(1,nFaces-1)*64 B
 namespace {
 
 struct HostBVH {
-  std::vector<Node64> nodes; std::vector<Tri48> tris; std::vector<TriShade> shade;
+  std::vector<Node128> nodes; std::vector<Tri48> tris; std::vector<TriShade> shade;
   int rootRef = kEmptyRef; int depth = 0;
 };
 
-static int subtree_depth(const std::vector<Node64>& nodes, int ref) {
+static int subtree_depth(const std::vector<Node128>& nodes, int ref) {
   if (ref < 0) return 0;
   // iterative to be safe on deep LBVHs
   int best = 0;
@@ -57,8 +57,8 @@ static int subtree_depth(const std::vector<Node64>& nodes, int ref) {
   while (!st.empty()) {
     auto [r, d] = st.back(); st.pop_back();
     best = std::max(best, d);
-    if (nodes[r].c0 >= 0) st.push_back({ nodes[r].c0, d + 1 });
-    if (nodes[r].c1 >= 0) st.push_back({ nodes[r].c1, d + 1 });
+    for (int k = 0; k < nodes[r].count; k++)
+      if (nodes[r].ref[k] >= 0) st.push_back({ nodes[r].ref[k], d + 1 });
   }
   return best;
 }
@@ -126,23 +126,39 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
       ihi[i] = mk3(fmaxf_(c.x, d.x), fmaxf_(c.y, d.y), fmaxf_(c.z, d.z));
     }
   }
+  // widening: survivors of the collapse at even depth become four-wide nodes (pt_lbvh.h)
+  std::vector<int> left(ni), right(ni), parentI(ni, -1);
+  for (int i = 0; i < ni; i++) { left[i] = kn[i].left; right[i] = kn[i].right; }
+  for (int i = 0; i < ni; i++) { if (left[i] >= 0) parentI[left[i]] = i; if (right[i] >= 0) parentI[right[i]] = i; }
   std::vector<int> newIndex(ni, -1);
   int nKept = 0;
-  for (int i = 0; i < ni; i++) if (last[i] - first[i] + 1 > leafSize) newIndex[i] = nKept++;
+  const float* iloF = reinterpret_cast<const float*>(ilo.data());
+  const float* ihiF = reinterpret_cast<const float*>(ihi.data());
+  static_assert(sizeof(v3) == 12, "v3 arrays are read as packed floats");
+  for (int i = 0; i < ni; i++)
+    if (wide_level(i, left.data(), right.data(), first.data(), last.data(), parentI.data(), leafSize, iloF, ihiF) > 0) newIndex[i] = nKept++;
   out.nodes.resize(nKept);
   auto box_of = [&](int child, v3& blo, v3& bhi) {
     if (child < 0) { blo = llo[~child]; bhi = lhi[~child]; } else { blo = ilo[child]; bhi = ihi[child]; }
   };
   for (int i = 0; i < ni; i++) {
     if (newIndex[i] < 0) continue;
-    Node64 nd; memset(&nd, 0, sizeof(nd));
-    v3 l0, h0, l1, h1;
-    box_of(kn[i].left, l0, h0); box_of(kn[i].right, l1, h1);
-    nd.a.x = l0.x; nd.a.y = l0.y; nd.a.z = l0.z; nd.a.w = h0.x;
-    nd.b.x = h0.y; nd.b.y = h0.z; nd.b.z = l1.x; nd.b.w = l1.y;
-    nd.c.x = l1.z; nd.c.y = h1.x; nd.c.z = h1.y; nd.c.w = h1.z;
-    nd.c0 = collapsed_ref(kn[i].left, first.data(), last.data(), newIndex.data(), leafSize);
-    nd.c1 = collapsed_ref(kn[i].right, first.data(), last.data(), newIndex.data(), leafSize);
+    Node128 nd; memset(&nd, 0, sizeof(nd));
+    int ch[4], opened[2];
+    const int nc = wide_children(i, left.data(), right.data(), first.data(), last.data(), leafSize, iloF, ihiF, ch, opened);
+    float lo4[3][4] = { { 0 } }, hi4[3][4] = { { 0 } };
+    for (int k = 0; k < 4; k++) {
+      if (k < nc) {
+        v3 bl, bh; box_of(ch[k], bl, bh);
+        lo4[0][k] = bl.x; lo4[1][k] = bl.y; lo4[2][k] = bl.z; hi4[0][k] = bh.x; hi4[1][k] = bh.y; hi4[2][k] = bh.z;
+        nd.ref[k] = collapsed_ref(ch[k], first.data(), last.data(), newIndex.data(), leafSize);
+      } else nd.ref[k] = kEmptyRef;
+    }
+    nd.lox = mk4(lo4[0][0], lo4[0][1], lo4[0][2], lo4[0][3]); nd.loy = mk4(lo4[1][0], lo4[1][1], lo4[1][2], lo4[1][3]);
+    nd.loz = mk4(lo4[2][0], lo4[2][1], lo4[2][2], lo4[2][3]);
+    nd.hix = mk4(hi4[0][0], hi4[0][1], hi4[0][2], hi4[0][3]); nd.hiy = mk4(hi4[1][0], hi4[1][1], hi4[1][2], hi4[1][3]);
+    nd.hiz = mk4(hi4[2][0], hi4[2][1], hi4[2][2], hi4[2][3]);
+    nd.count = nc;
     out.nodes[newIndex[i]] = nd;
   }
   out.rootRef = 0;
@@ -203,7 +219,7 @@ extern "C" {
 int hostsim_build_bvh(const hostsim_scene* s, int leafSize, hostsim_bvh_out* out) {
   HostBVH b; build_lbvh(*s, leafSize, b);
   out->nNodes = (int)b.nodes.size(); out->rootRef = b.rootRef; out->depth = b.depth;
-  if (out->nodes && !b.nodes.empty()) memcpy(out->nodes, b.nodes.data(), b.nodes.size() * sizeof(Node64));
+  if (out->nodes && !b.nodes.empty()) memcpy(out->nodes, b.nodes.data(), b.nodes.size() * sizeof(Node128));
   if (out->tris && !b.tris.empty()) memcpy(out->tris, b.tris.data(), b.tris.size() * sizeof(Tri48));
   if (out->triPrim) for (size_t i = 0; i < b.tris.size(); i++) out->triPrim[i] = b.tris[i].prim;
   return 0;

@@ -27,8 +27,13 @@ def test_lbvh_mirror_is_a_valid_bvh(leaf):
     nodes, tris, prim, root, depth = hostsim_bvh(hs, leaf)
     n = hs.sizes.nFaces
     assert sorted(prim.tolist()) == list(range(n))                       # every face exactly once
-    assert root == 0 and 10 < depth < 64
-    c = nodes[:, 12:14].view(np.int32)
+    assert root == 0 and 5 < depth < 32
+    # Node128: words 0..23 = lox loy loz hix hiy hiz (4 children each), 24..27 = refs, 28 = count
+    EMPTY = 0x7ffffffe
+    c = nodes[:, 24:28].view(np.int32)
+    cnt = nodes[:, 28].view(np.int32)
+    assert cnt.min() >= 2 and cnt.max() == 4 and ((c != EMPTY).sum(axis=1) == cnt).all()
+    assert cnt.mean() > 3.0                                              # mostly full four-wide nodes
     leaves = c[c < 0]
     first, count = (~leaves) >> 3, ((~leaves) & 7) + 1
     assert count.max() <= leaf and count.sum() == n
@@ -36,17 +41,16 @@ def test_lbvh_mirror_is_a_valid_bvh(leaf):
     for f, k in zip(first, count):
         covered[f:f + k] += 1
     assert (covered == 1).all()                                          # leaves partition the sorted records
-    internal = c[c >= 0]
+    internal = c[(c >= 0) & (c != EMPTY)]
     assert len(internal) == len(nodes) - 1 and len(set(internal.tolist())) == len(internal)   # a tree
     # child boxes contain their triangles (first leaf of every node, spot check)
-    boxes = nodes[:, :12].view(np.float32)
+    boxes = nodes[:, :24].view(np.float32).reshape(len(nodes), 6, 4)       # [node, lox..hiz, child]
     p0 = tris[:, 0:3].view(np.float32); e0 = tris[:, 4:7].view(np.float32); e1 = tris[:, 8:11].view(np.float32)
     for i in range(0, len(nodes), 997):
         for side, ref in enumerate(c[i]):
             if ref >= 0:
                 continue
-            lo = boxes[i, 0:3] if side == 0 else boxes[i, 6:9]
-            hi = boxes[i, 3:6] if side == 0 else boxes[i, 9:12]
+            lo, hi = boxes[i, 0:3, side], boxes[i, 3:6, side]
             f, k = (~ref) >> 3, ((~ref) & 7) + 1
             v = np.concatenate([p0[f:f + k], p0[f:f + k] + e0[f:f + k], p0[f:f + k] - e1[f:f + k]])
             assert (v >= lo - 1e-6).all() and (v <= hi + 1e-6).all()

@@ -34,7 +34,7 @@ def main():
         seeds = M.launch_seeds(8)
         ctx.accum_clear(); st = ctx.render_counted(seeds)
         rays = st.rays
-        B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+        B = 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
         print("   counters", st.as_dict(), "bytes/ray %.1f" % (B / rays), "lane util %.3f" % (st.activeLaneSteps / max(1, 64 * st.traversalSteps)))
         for thr in (1, 16, 32, 40, 48, 56, 64):
             for bpc in (2, 4):

@@ -11,7 +11,7 @@ seeds = M.launch_seeds(spp)
 ctx.load(hs)
 ctx.accum_clear(); st = ctx.render_counted(seeds)
 rays = st.rays
-B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+B = 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
 def run(tag):
     best = 1e9
     for rep in range(2):

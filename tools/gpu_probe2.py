@@ -31,7 +31,7 @@ for P in (128, 192, 256):
             ctx.set_option("refill_lanes", refill); ctx.set_option("starve_lanes", starve)
             ctx.accum_clear(); st = ctx.render_counted(seeds)
             rays = st.rays
-            B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+            B = 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
             ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); ms, n = ctx.kernel_time()
             img = ctx.accum_read()
             if ref is None: ref = img

@@ -12,7 +12,7 @@ ctx.load(hs)
 ctx.set_option("kernel_variant", 1)
 ctx.accum_clear(); st = ctx.render_counted(seeds)
 rays = st.rays
-B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+B = 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
 print("spp", spp, "rays", rays, "rays/sample %.3f" % (rays / st.samples), "bytes/ray %.1f" % (B / rays), "trav util %.3f batch fill %.1f" % (
     st.activeLaneSteps / max(1, 64 * st.traversalSteps), st.shadeBatchLanes / max(1, st.shadeBatches)))
 def run(tag):

@@ -21,7 +21,7 @@ for leaf in (4, 2, 8):
     ctx.set_option("kernel_variant", 1)
     ctx.accum_clear(); st = ctx.render_counted(seeds)
     rays = st.rays
-    B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+    B = 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
     print("leaf", leaf, "bytes/ray %.1f" % (B / rays), "step util %.3f batch fill %.1f" % (st.activeLaneSteps / max(1, 64 * st.traversalSteps), st.shadeBatchLanes / max(1, st.shadeBatches)))
     for lt in (8, 16, 24, 32):
         ctx.set_option("leaf_threshold", lt)

@@ -12,7 +12,7 @@ ctx.load(hs)
 ctx.set_option("kernel_variant", 1)
 ctx.accum_clear(); st = ctx.render_counted(seeds)
 rays = st.rays
-B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+B = 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
 img0 = ctx.accum_read()
 import hashlib
 print(os.environ.get("MOPTIX_DEVICE_LIB", "default"), "hash", hashlib.md5(img0.tobytes()).hexdigest()[:12])

@@ -18,7 +18,7 @@ ctx.load(hs)
 ctx.set_option("kernel_variant", 2)
 ctx.accum_clear(); st = ctx.render_counted(seeds)
 rays = st.rays
-B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+B = 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
 ref = None
 def run(tag):
     global ref

@@ -13,7 +13,7 @@ def setup(leaf):
     ctx.set_option("leaf_size", leaf); ctx.load(hs)
     ctx.accum_clear(); st = ctx.render_counted(seeds)
     rays = st.rays
-    B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+    B = 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
     print("leaf", leaf, "bytes/ray %.1f nodes/ray %.2f tris/ray %.2f" % (B / rays, st.nodeFetches / rays, st.triTests / rays), flush=True)
 def run(tag):
     best = 1e9
