@@ -137,13 +137,23 @@ __global__ void k_fit(int n, const int* __restrict__ left, const int* __restrict
   }
 }
 
-// 6a/7a. which Karras nodes become four-wide nodes, and on which level (0 = none)
-__global__ void k_kept(int ni, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ first,
-                       const int* __restrict__ last, const int* __restrict__ parentI, int leafSize,
-                       const float* __restrict__ ilo, const float* __restrict__ ihi, int* __restrict__ kept, int* depthOut) {
+// 6a. what every surviving node would absorb if it became a four-wide node
+__global__ void k_opened(int ni, const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ first,
+                         const int* __restrict__ last, int leafSize, const float* __restrict__ ilo, const float* __restrict__ ihi,
+                         int* __restrict__ opened) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ni) return;
+  int ch[4], op[2] = { -1, -1 };
+  if (karras_kept(i, first, last, leafSize)) wide_children(i, left, right, first, last, leafSize, ilo, ihi, ch, op);
+  opened[2 * (size_t)i] = op[0]; opened[2 * (size_t)i + 1] = op[1];
+}
+
+// 7a. which Karras nodes become four-wide nodes, and on which level (0 = none)
+__global__ void k_kept(int ni, const int* __restrict__ first, const int* __restrict__ last, const int* __restrict__ parentI,
+                       int leafSize, const int* __restrict__ opened, int* __restrict__ kept, int* depthOut) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int d = 0;
-  if (i < ni) { d = wide_level(i, left, right, first, last, parentI, leafSize, ilo, ihi); kept[i] = d > 0 ? 1 : 0; }
+  if (i < ni) { d = wide_level(i, first, last, parentI, leafSize, opened); kept[i] = d > 0 ? 1 : 0; }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) d = max(d, __shfl_xor(d, o));
   if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(depthOut, d);
@@ -207,7 +217,7 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
 
   float *lo = nullptr, *hi = nullptr, *leafLo = nullptr, *leafHi = nullptr, *ilo = nullptr, *ihi = nullptr;
   uint64_t *keys = nullptr, *keysSorted = nullptr;
-  int *left = nullptr, *right = nullptr, *first = nullptr, *last = nullptr, *parentI = nullptr, *parentL = nullptr, *kept = nullptr, *newIndex = nullptr;
+  int *left = nullptr, *right = nullptr, *first = nullptr, *last = nullptr, *parentI = nullptr, *parentL = nullptr, *kept = nullptr, *newIndex = nullptr, *opened = nullptr;
   unsigned int* arrivals = nullptr; SceneBox* box = nullptr; int* dDepth = nullptr; void* tmp = nullptr;
   size_t tmpSort = 0, tmpScan = 0, tmpBytes = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -219,7 +229,7 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
   LB_CHECK(dmalloc(&ilo, 3 * (size_t)ni)); LB_CHECK(dmalloc(&ihi, 3 * (size_t)ni));
   LB_CHECK(dmalloc(&keys, (size_t)n)); LB_CHECK(dmalloc(&keysSorted, (size_t)n));
   LB_CHECK(dmalloc(&left, (size_t)ni)); LB_CHECK(dmalloc(&right, (size_t)ni)); LB_CHECK(dmalloc(&first, (size_t)ni)); LB_CHECK(dmalloc(&last, (size_t)ni));
-  LB_CHECK(dmalloc(&parentI, (size_t)ni)); LB_CHECK(dmalloc(&parentL, (size_t)n)); LB_CHECK(dmalloc(&kept, (size_t)ni + 1)); LB_CHECK(dmalloc(&newIndex, (size_t)ni + 1));
+  LB_CHECK(dmalloc(&parentI, (size_t)ni)); LB_CHECK(dmalloc(&parentL, (size_t)n)); LB_CHECK(dmalloc(&kept, (size_t)ni + 1)); LB_CHECK(dmalloc(&newIndex, (size_t)ni + 1)); LB_CHECK(dmalloc(&opened, 2 * (size_t)ni + 2));
   LB_CHECK(dmalloc(&arrivals, (size_t)ni)); LB_CHECK(dmalloc(&box, 1)); LB_CHECK(dmalloc(&dDepth, 1));
   LB_CHECK(dmalloc(&out->tris, (size_t)n)); LB_CHECK(dmalloc(&out->shade, (size_t)n));
   LB_CHECK(rocprim::radix_sort_keys(nullptr, tmpSort, keys, keysSorted, (size_t)n, 0, 64, stream));
@@ -242,7 +252,8 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
     LB_CHECK(hipMemsetAsync(dDepth, 0, sizeof(int), stream));
     k_karras<<<grid_for(ni), kBlock, 0, stream>>>(n, keysSorted, left, right, first, last, parentI, parentL);
     k_fit<<<grid_for(n), kBlock, 0, stream>>>(n, left, right, parentI, parentL, leafLo, leafHi, ilo, ihi, arrivals);
-    k_kept<<<grid_for(ni), kBlock, 0, stream>>>(ni, left, right, first, last, parentI, leafSize, ilo, ihi, kept, dDepth);
+    k_opened<<<grid_for(ni), kBlock, 0, stream>>>(ni, left, right, first, last, leafSize, ilo, ihi, opened);
+    k_kept<<<grid_for(ni), kBlock, 0, stream>>>(ni, first, last, parentI, leafSize, opened, kept, dDepth);
     LB_CHECK(rocprim::exclusive_scan(tmp, tmpScan, kept, newIndex, 0, (size_t)ni, rocprim::plus<int>(), stream));
     LB_CHECK(hipMemcpyAsync(&hostCount[0], newIndex + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
     LB_CHECK(hipMemcpyAsync(&hostCount[1], kept + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -262,7 +273,7 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
 done:
   for (void* p : { (void*)lo, (void*)hi, (void*)leafLo, (void*)leafHi, (void*)ilo, (void*)ihi, (void*)keys, (void*)keysSorted,
                    (void*)left, (void*)right, (void*)first, (void*)last, (void*)parentI, (void*)parentL, (void*)kept, (void*)newIndex,
-                   (void*)arrivals, (void*)box, (void*)dDepth, tmp })
+                   (void*)arrivals, (void*)box, (void*)dDepth, (void*)opened, tmp })
     if (p) (void)hipFree(p);
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(kBlockThreads) pt_megakernel(const LaunchArgs 
   ps.N = mk3(0, 0, 1); ps.V = mk3(0, 0, 1); ps.mat = 0; ps.light = 0; ps.pendW = mk3(0, 0, 0); ps.pendInv = 0;
   Trav tv;
   tv.node = kTravDone; tv.sp = 0; tv.started = 0; tv.tbest = 0; tv.bestPrim = -1; tv.bestTri = -1;
-  tv.beta = 0; tv.gamma = 0; tv.att = mk3(1, 1, 1); tv.inv = mk3(0, 0, 0);
+  tv.beta = 0; tv.gamma = 0; tv.att = mk3(1, 1, 1); tv.inv = mk3(0, 0, 0); tv.noi = mk3(0, 0, 0);
   Counters ct = {};
   uint32_t waveSteps = 0, activeLaneSteps = 0;
 

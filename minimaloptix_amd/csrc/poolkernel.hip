@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(kBlockThreads, PT_POOL_WAVES_PER_SIMD) pt_pool
   PathState ray;                  // only o, d, tmin, tmax, kind are used here
   ray.mode = M_TRACE; ray.tmin = sc.epsT; ray.o = mk3(0, 0, 0); ray.d = mk3(0, 0, 1); ray.tmax = 0; ray.kind = RK_RADIANCE;
   Trav tv; tv.node = kTravDone; tv.sp = 0; tv.started = 0; tv.tbest = 0; tv.bestPrim = -1; tv.bestTri = -1;
-  tv.beta = 0; tv.gamma = 0; tv.att = mk3(1, 1, 1); tv.inv = mk3(0, 0, 0);
+  tv.beta = 0; tv.gamma = 0; tv.att = mk3(1, 1, 1); tv.inv = mk3(0, 0, 0); tv.noi = mk3(0, 0, 0);
   Counters ct = {};
   uint32_t leafPasses = 0, leafLanes = 0, waveSteps = 0, activeLaneSteps = 0, batchLanes = 0, batches = 0, dbgFull = 0, dbgIdle = 0, dbgWaiting = 0; unsigned long long tBatch = 0, tRefill = 0, tNode = 0, tLeaf = 0, tFin = 0, tStamp = 0; const unsigned long long tStart = CNT ? __builtin_amdgcn_s_memtime() : 0ull;
 #define PT_STAMP(acc) do { if (CNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tStamp; tStamp = now_; } } while (0)

@@ -141,9 +141,10 @@ PT_HD int wide_children(int r, const int* left, const int* right, const int* fir
 }
 // Level (1 = root) of Karras node i in the wide tree, or 0 when i does not survive or is absorbed by a wide
 // node above it.  Decided by replaying the choices along the path from the root: O(depth) work per node, no
-// communication between nodes, same answer on every run.  Keys are 64 bits, so a path has at most 64 nodes.
-PT_HD int wide_level(int i, const int* left, const int* right, const int* first, const int* last, const int* parentI,
-                     int leafSize, const float* ilo, const float* ihi) {
+// communication between nodes, same answer on every run.  opened[2*r], opened[2*r+1] hold the nodes that r would
+// absorb as a wide node (wide_children, computed once per surviving node).  Keys are 64 bits, so a path has at
+// most 64 nodes.
+PT_HD int wide_level(int i, const int* first, const int* last, const int* parentI, int leafSize, const int* opened) {
   if (!karras_kept(i, first, last, leafSize)) return 0;
   int path[66]; int np = 0;
   for (int p = i; p >= 0 && np < 66; p = parentI[p]) path[np++] = p;
@@ -151,10 +152,9 @@ PT_HD int wide_level(int i, const int* left, const int* right, const int* first,
   for (;;) {
     const int cur = path[k];
     if (cur == i) return level;
-    int ch[4], op[2];
-    wide_children(cur, left, right, first, last, leafSize, ilo, ihi, ch, op);
+    const int op0 = opened[2 * (size_t)cur], op1 = opened[2 * (size_t)cur + 1];
     k--;
-    while (path[k] == op[0] || path[k] == op[1]) { if (path[k] == i) return 0; k--; }
+    while (path[k] == op0 || path[k] == op1) { if (path[k] == i) return 0; k--; }
     level++;
   }
 }

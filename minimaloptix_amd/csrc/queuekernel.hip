@@ -37,7 +37,8 @@ constexpr int kP = 128;                 // slots per wave
 constexpr int kStackN = 11;             // LDS stack entries per slot; deeper levels spill to HBM
 constexpr int kWavesPerSimd = 3;        // occupancy target: 3 workgroups per CU (VGPR <= 168, LDS <= 53 KB)
 
-enum { Q_NODE = 0, Q_LEAF = 1, Q_SHADE = 2, Q_GEN = 3, kNumQ = 4, DEST_DONE = 4, DEST_NONE = -1 };
+// pool-wide queues first (they index PoolLds::queue); Q_NODE / Q_LEAF are per-wave rings (WavePriv)
+enum { Q_SHADE = 0, Q_GEN = 1, kNumQ = 2, Q_NODE = 2, Q_LEAF = 3, DEST_DONE = 4, DEST_NONE = -1 };
 
 struct alignas(16) SlotCold {           // 9 x 16 B, HBM, private to the pool
   // path payload (shading / regeneration batches only)
@@ -100,7 +101,9 @@ struct PoolLds {
 template <int NS>
 struct WavePriv {
   unsigned short qnode[NS];        // node-ready slots owned by this wave (ring)
-  unsigned short outbox[3][128];   // slots on their way to the pool's Q_LEAF / Q_SHADE / Q_GEN
+  // One loop iteration pushes at most 128 slots (results of the last pass + lanes leaving the node loop).
+  unsigned short qleaf[256];       // slots standing at a leaf, owned by this wave (ring; a pass runs at 64: < 64 + 128)
+  unsigned short outbox[2][160];   // slots on their way to the pool's Q_SHADE / Q_GEN (flushed at 32: < 32 + 128)
 };
 
 typedef __attribute__((address_space(3))) int lds_int;
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
 #define PT_SUB0() do { if (CNT) tSub = __builtin_amdgcn_s_memtime(); } while (0)
 #define PT_SUB(acc) do { if (CNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tSub; tSub = now_; } } while (0)
   // queue bookkeeping: registers (wave-uniform); with SHARED they mirror LDS inside a transaction
-  int qHead[kNumQ] = { 0, 0, 0, 0 }, qCount[kNumQ] = { 0, 0, 0, 0 };
+  int qHead[kNumQ] = { 0, 0 }, qCount[kNumQ] = { 0, 0 };
   int nDone = 0;
 
   [[maybe_unused]] auto q_push = [&](int q, bool pred, int slot) {
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
   PathState nray;              // o, tmin used
   nray.o = mk3(0, 0, 0); nray.tmin = sc.epsT; nray.d = mk3(0, 0, 1); nray.tmax = 0; nray.kind = RK_RADIANCE; nray.mode = M_TRACE;
   Trav ntv;                    // inv, tbest, node, sp used
-  ntv.node = kTravDone; ntv.sp = 0; ntv.tbest = 0; ntv.inv = mk3(0, 0, 0); ntv.bestPrim = -1; ntv.bestTri = -1;
+  ntv.node = kTravDone; ntv.sp = 0; ntv.tbest = 0; ntv.inv = mk3(0, 0, 0); ntv.noi = mk3(0, 0, 0); ntv.bestPrim = -1; ntv.bestTri = -1;
   ntv.beta = 0; ntv.gamma = 0; ntv.att = mk3(1, 1, 1); ntv.started = 1;
 
   // result of the last pass, queued inside the next transaction
@@ -250,6 +253,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     const bool have = slot >= 0;
     if (CNT) { leafPasses++; leafLanes += (uint32_t)__popcll(__ballot(have)); }
     pendSlot = slot; pendDest = DEST_NONE;
+    // slot records written by earlier passes of this wave (other lanes) or published by other waves: the stores
+    // of the previous pass were left in flight, so they are ordered here, where their latency has already elapsed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (have) {
       PathState ps; Trav tv;
@@ -295,6 +301,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     PathState ps; Trav res;
     ps.mode = M_DONE; ps.kind = RK_RADIANCE;
     res.node = kTravDone; res.bestPrim = -1;
+    // slot records written by earlier passes of this wave (other lanes) or published by other waves: the stores
+    // of the previous pass were left in flight, so they are ordered here, where their latency has already elapsed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (have) {
       const SlotCold c = slot_load(cold + slot);
@@ -362,7 +371,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
   // two transactions
   unsigned short* myNodeQ = sPriv[wave].qnode;
   int nqHead = 0, nqCount = 0;
-  int obCount[3] = { 0, 0, 0 };            // out-boxes for Q_LEAF, Q_SHADE, Q_GEN
+  unsigned short* myLeafQ = sPriv[wave].qleaf;
+  int lqHead = 0, lqCount = 0;             // leaf-ready ring: leaf passes need no queue transaction
+  int obCount[2] = { 0, 0 };               // out-boxes for Q_SHADE, Q_GEN
   int localDone = 0;
   auto local_push = [&](int dest, int slot) {   // wave-collective; dest per lane
     {
@@ -372,10 +383,17 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         nqCount += __popcll(m);
       }
     }
-    for (int d = 0; d < 3; d++) {
-      const unsigned long long m = __ballot(dest == Q_LEAF + d);
+    {
+      const unsigned long long m = __ballot(dest == Q_LEAF);
       if (m != 0ull) {
-        if (dest == Q_LEAF + d) sPriv[wave].outbox[d][obCount[d] + lane_rank(m)] = (unsigned short)slot;
+        if (dest == Q_LEAF) myLeafQ[(lqHead + lqCount + lane_rank(m)) & 255] = (unsigned short)slot;
+        lqCount += __popcll(m);
+      }
+    }
+    for (int d = 0; d < 2; d++) {
+      const unsigned long long m = __ballot(dest == Q_SHADE + d);
+      if (m != 0ull) {
+        if (dest == Q_SHADE + d) sPriv[wave].outbox[d][obCount[d] + lane_rank(m)] = (unsigned short)slot;
         obCount[d] += __popcll(m);
       }
     }
@@ -410,6 +428,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
             const int spw = W.stack[ns][0];
             nray.o = mk3(na.x, na.y, na.z); ntv.tbest = na.w;
             ntv.inv = mk3(nb.x, nb.y, nb.z); ntv.node = f2i(nb.w);
+            ntv.noi = neg_o_inv(nray.o, ntv.inv);
             ntv.sp = spw & ~kShadeFlag; nsFlag = spw & kShadeFlag;
           }
         }
@@ -420,12 +439,22 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     const bool starving = nActive <= 64 - a.starveLanes;
     int pass = -1;      // -1 node loop, 0 leaf, 1 shade, 2 gen, 3 idle, 4 exit
     int mySlot = -1;
-    if (starving || obCount[0] >= 32 || obCount[1] >= 32 || obCount[2] >= 32) {
+    auto leaf_pop = [&]() -> int {              // up to 64 slots from this wave's own leaf ring
+      const int n = min(64, lqCount);
+      const int slot = lane < n ? (int)myLeafQ[(lqHead + lane) & 255] : -1;
+      lqHead = (lqHead + n) & 255; lqCount -= n;
+      return slot;
+    };
+    const bool flush = obCount[0] >= 32 || obCount[1] >= 32;      // out-boxes are bounded: flushing comes first
+    if (!flush && (lqCount >= 64 || (starving && lqCount >= 32))) {
+      pass = 0; mySlot = leaf_pop();
+      PT_SUB(tLocal);
+    } else if (starving || flush) {
       // =========================== queue transaction ===========================
       PT_SUB(tLocal);
       txn_begin();
-      for (int d = 0; d < 3; d++) {
-        const int q = Q_LEAF + d;
+      for (int d = 0; d < 2; d++) {
+        const int q = Q_SHADE + d;
         for (int base = 0; base < obCount[d]; base += 64) {
           const int i = base + lane;
           if (i < obCount[d]) W.queue[q][(qHead[q] + qCount[q] + i) & (NS - 1)] = sPriv[wave].outbox[d][i];
@@ -435,14 +464,15 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       nDone += localDone; localDone = 0;
       if (qCount[Q_SHADE] >= 64) pass = 1;
       else if (qCount[Q_GEN] >= 64) pass = 2;
-      else if (qCount[Q_LEAF] >= 64) pass = 0;
+      else if (lqCount >= 64) pass = 0;
       else if (starving) {
-        const int l = qCount[Q_LEAF], sh = qCount[Q_SHADE], g = qCount[Q_GEN];
+        const int l = lqCount, sh = qCount[Q_SHADE], g = qCount[Q_GEN];
         if (l + sh + g == 0) { if (nActive == 0) pass = (nDone == NS) ? 4 : 3; }
         else pass = (l >= sh && l >= g) ? 0 : (sh >= g ? 1 : 2);
       }
-      if (pass >= 0 && pass <= 2) mySlot = q_pop(pass == 0 ? Q_LEAF : (pass == 1 ? Q_SHADE : Q_GEN), true);
+      if (pass == 1 || pass == 2) mySlot = q_pop(pass == 1 ? Q_SHADE : Q_GEN, true);
       txn_end();
+      if (pass == 0) mySlot = leaf_pop();
       PT_SUB(tTxn);
       // =========================================================================
     } else PT_SUB(tLocal);

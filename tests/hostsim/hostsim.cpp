@@ -63,6 +63,50 @@ static int subtree_depth(const std::vector<Node128>& nodes, int ref) {
   return best;
 }
 
+// Experiment only (HOSTSIM_SAH=1): top-down binned-SAH binary tree in the same array form as the Karras tree,
+// to measure how much a better tree would save in node fetches / triangle tests.
+struct SahBuilder {
+  const std::vector<v3>&lo, &hi, &cen; std::vector<int> ids; std::vector<KarrasNode> nodes;
+  static float area(v3 a, v3 b) { const v3 d = b - a; return d.x * d.y + d.y * d.z + d.z * d.x; }
+  static float comp(v3 v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
+  int build(int b, int e) {   // returns child ref: >=0 node, <0 ~position
+    if (e - b == 1) return ~b;
+    const int id = (int)nodes.size(); nodes.push_back(KarrasNode{ 0, 0, b, e - 1 });
+    v3 clo = mk3(1e37f, 1e37f, 1e37f), chi = mk3(-1e37f, -1e37f, -1e37f);
+    for (int k = b; k < e; k++) { const v3 c = cen[ids[k]];
+      clo = mk3(fminf_(clo.x, c.x), fminf_(clo.y, c.y), fminf_(clo.z, c.z)); chi = mk3(fmaxf_(chi.x, c.x), fmaxf_(chi.y, c.y), fmaxf_(chi.z, c.z)); }
+    const int NB = 16; float bestCost = 1e38f; int bestAxis = -1, bestBin = -1;
+    for (int a = 0; a < 3; a++) {
+      const float ext = comp(chi, a) - comp(clo, a);
+      if (!(ext > 0.f)) continue;
+      v3 blo[NB], bhi[NB]; int cnt[NB];
+      for (int i = 0; i < NB; i++) { blo[i] = mk3(1e37f, 1e37f, 1e37f); bhi[i] = mk3(-1e37f, -1e37f, -1e37f); cnt[i] = 0; }
+      for (int k = b; k < e; k++) { const int f = ids[k];
+        int bi = (int)((comp(cen[f], a) - comp(clo, a)) / ext * NB); if (bi >= NB) bi = NB - 1; if (bi < 0) bi = 0;
+        cnt[bi]++; blo[bi] = mk3(fminf_(blo[bi].x, lo[f].x), fminf_(blo[bi].y, lo[f].y), fminf_(blo[bi].z, lo[f].z));
+        bhi[bi] = mk3(fmaxf_(bhi[bi].x, hi[f].x), fmaxf_(bhi[bi].y, hi[f].y), fmaxf_(bhi[bi].z, hi[f].z)); }
+      float la[NB]; int lc[NB]; v3 l0 = mk3(1e37f, 1e37f, 1e37f), l1 = mk3(-1e37f, -1e37f, -1e37f); int c = 0;
+      for (int i = 0; i < NB; i++) { if (cnt[i]) { l0 = mk3(fminf_(l0.x, blo[i].x), fminf_(l0.y, blo[i].y), fminf_(l0.z, blo[i].z)); l1 = mk3(fmaxf_(l1.x, bhi[i].x), fmaxf_(l1.y, bhi[i].y), fmaxf_(l1.z, bhi[i].z)); } c += cnt[i]; la[i] = c ? area(l0, l1) : 0.f; lc[i] = c; }
+      v3 r0 = mk3(1e37f, 1e37f, 1e37f), r1 = mk3(-1e37f, -1e37f, -1e37f); c = 0;
+      for (int i = NB - 1; i >= 1; i--) { if (cnt[i]) { r0 = mk3(fminf_(r0.x, blo[i].x), fminf_(r0.y, blo[i].y), fminf_(r0.z, blo[i].z)); r1 = mk3(fmaxf_(r1.x, bhi[i].x), fmaxf_(r1.y, bhi[i].y), fmaxf_(r1.z, bhi[i].z)); } c += cnt[i];
+        if (c == 0 || lc[i - 1] == 0) continue;
+        const float cost = la[i - 1] * lc[i - 1] + area(r0, r1) * c;
+        if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = i; } }
+    }
+    int mid;
+    if (bestAxis < 0) mid = (b + e) / 2;
+    else {
+      const float ext = comp(chi, bestAxis) - comp(clo, bestAxis), base = comp(clo, bestAxis);
+      auto binOf = [&](int f) { int bi = (int)((comp(cen[f], bestAxis) - base) / ext * NB); if (bi >= NB) bi = NB - 1; if (bi < 0) bi = 0; return bi; };
+      mid = (int)(std::stable_partition(ids.begin() + b, ids.begin() + e, [&](int f) { return binOf(f) < bestBin; }) - ids.begin());
+      if (mid == b || mid == e) mid = (b + e) / 2;
+    }
+    const int l = build(b, mid); const int r = build(mid, e);
+    nodes[id].left = l; nodes[id].right = r;
+    return id;
+  }
+};
+
 static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   const int n = s.nFaces;
   out.nodes.clear(); out.tris.clear(); out.shade.clear(); out.rootRef = kEmptyRef; out.depth = 0;
@@ -85,6 +129,13 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   const int idxBits = lbvh_index_bits(n), bitsPerAxis = getenv("HOSTSIM_MORTON30") ? 10 : lbvh_bits_per_axis(n);
   for (int f = 0; f < n; f++) keys[f] = morton_key(cen[f], clo, invExt, bitsPerAxis, idxBits, f);
   std::sort(keys.begin(), keys.end());
+  SahBuilder sah{ lo, hi, cen, {}, {} };
+  const bool useSah = getenv("HOSTSIM_SAH") != nullptr && n > 1;
+  if (useSah) {
+    sah.ids.resize(n); for (int k = 0; k < n; k++) sah.ids[k] = key_face(keys[k], idxBits);
+    sah.build(0, n);
+    for (int k = 0; k < n; k++) keys[k] = ((uint64_t)k << idxBits) | (uint64_t)sah.ids[k];
+  }
 
   out.tris.resize(n); out.shade.resize(n);
   std::vector<v3> llo(n), lhi(n);
@@ -109,7 +160,7 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   const int ni = n - 1;
   std::vector<KarrasNode> kn(ni);
   std::vector<int> first(ni), last(ni);
-  for (int i = 0; i < ni; i++) { kn[i] = karras_node(keys.data(), n, i); first[i] = kn[i].first; last[i] = kn[i].last; }
+  for (int i = 0; i < ni; i++) { kn[i] = useSah ? sah.nodes[i] : karras_node(keys.data(), n, i); first[i] = kn[i].first; last[i] = kn[i].last; }
   // boxes of every Karras node = union of the leaf boxes in its range (what the device's
   // bottom-up atomic pass produces; min/max are exact so the order does not matter)
   std::vector<v3> ilo(ni), ihi(ni);
@@ -135,8 +186,15 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   const float* iloF = reinterpret_cast<const float*>(ilo.data());
   const float* ihiF = reinterpret_cast<const float*>(ihi.data());
   static_assert(sizeof(v3) == 12, "v3 arrays are read as packed floats");
+  std::vector<int> openedBy(2 * (size_t)ni, -1);
+  for (int i = 0; i < ni; i++) {
+    int ch[4], op[2] = { -1, -1 };
+    if (karras_kept(i, first.data(), last.data(), leafSize))
+      wide_children(i, left.data(), right.data(), first.data(), last.data(), leafSize, iloF, ihiF, ch, op);
+    openedBy[2 * (size_t)i] = op[0]; openedBy[2 * (size_t)i + 1] = op[1];
+  }
   for (int i = 0; i < ni; i++)
-    if (wide_level(i, left.data(), right.data(), first.data(), last.data(), parentI.data(), leafSize, iloF, ihiF) > 0) newIndex[i] = nKept++;
+    if (wide_level(i, first.data(), last.data(), parentI.data(), leafSize, openedBy.data()) > 0) newIndex[i] = nKept++;
   out.nodes.resize(nKept);
   auto box_of = [&](int child, v3& blo, v3& bhi) {
     if (child < 0) { blo = llo[~child]; bhi = lhi[~child]; } else { blo = ilo[child]; bhi = ihi[child]; }

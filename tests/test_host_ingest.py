@@ -149,3 +149,33 @@ def test_animation_matches_oracle_restatement():
     cam = K.CamParams()
     K.host_lib().mohost_video_camera(angle.value, 16 / 9, C.byref(cam))
     assert abs(cam.origin.y - min(12.0, angle.value / 10 + 8.0)) < 1e-5 and abs(cam.lensRadius - 0.1) < 1e-7
+
+
+def test_sphere_light_scene_matches_oracle(tmp_path):
+    """`.scene` sphere lights (`radius`, `normal`), `name` lines and `properties`, rendered by
+    the device code path compiled for the host and by the oracle (NEE on a sphere light uses the rejection sampler)."""
+    from common import O, hostsim_render, oracle_scene, rmse
+    d = tmp_path / "hyperion"
+    d.mkdir()
+    (d / "floor.obj").write_text("v -2 0 -2\nv -2 0 2\nv 2 0 2\nv 2 0 -2\nvn 0 1 0\nf 1//1 2//1 3//1 4//1\n")
+    (d / "blade.obj").write_text("v -0.5 0.1 -0.3\nv 0.6 0.1 -0.2\nv 0.0 0.9 0.4\nf 1 2 3\n")
+    (d / "hyperion.scene").write_text(
+        "properties\n{\n\twidth 640\n\theight 480\n}\n"
+        "material Ground\n{\n\tname Ground\n\tcolor 0.7 0.6 0.5\n\troughness 0.3\n}\n"
+        "material Blade\n{\n\tcolor 0.2 0.4 0.9\n\tmetallic 0.8\n\troughness 0.2\n}\n"
+        "mesh\n{\n\tfile floor.obj\n\tmaterial Ground\n}\n"
+        "mesh\n{\n\tfile blade.obj\n\tmaterial Blade\n}\n"
+        "light\n{\n\ttype Sphere\n\tposition 0.3 1.6 -0.4\n\tradius 0.25\n\tnormal 0 -2 0\n\temission 20 18 16\n}\n")
+    hs = M.HostScene("file:hyperion", 72, 54, base_folder=str(tmp_path) + "/")
+    dd = hs.to_dict()
+    l = dd["lights"][0]
+    assert l["shape"] == K.LIGHT_SPHERE and np.isclose(l["area"], 4 * np.pi * 0.25 ** 2, rtol=1e-6)
+    assert np.allclose(l["normal"], [0, -1, 0])                              # scene.cpp:85 normalises it
+    assert hs.sizes.nSpheres == 1 and np.isclose(dd["spheres"][0][3], 0.25)  # the light's geometry (MinimalOptiX.cpp:497-503)
+    assert (dd["width"], dd["height"]) == (72, 54)
+    seeds = M.launch_seeds(6, 3)
+    ref, st = oracle_scene(hs).render(seeds)
+    got, cnt = hostsim_render(hs, seeds)
+    assert (cnt["primaryRays"], cnt["bounceRays"], cnt["shadowRays"]) == (st.primaryRays, st.bounceRays, st.shadowRays)
+    assert st.shadowRays > 0 and rmse(got, ref) / len(seeds) < 1e-5
+    assert ref.max() > 0.5                                                   # the light reaches the floor
