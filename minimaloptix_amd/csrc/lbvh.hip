@@ -151,9 +151,10 @@ __global__ void k_opened(int ni, const int* __restrict__ left, const int* __rest
 // 7a. which Karras nodes become four-wide nodes, and on which level (0 = none)
 __global__ void k_kept(int ni, const int* __restrict__ first, const int* __restrict__ last, const int* __restrict__ parentI,
                        int leafSize, const int* __restrict__ opened, int* __restrict__ kept, int* depthOut) {
+  __shared__ int sPath[kMaxKarrasPath][64];            // one column per thread: no scratch memory, no bank conflicts
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int d = 0;
-  if (i < ni) { d = wide_level(i, first, last, parentI, leafSize, opened); kept[i] = d > 0 ? 1 : 0; }
+  if (i < ni) { d = wide_level(i, first, last, parentI, leafSize, opened, &sPath[0][threadIdx.x], 64); kept[i] = d > 0 ? 1 : 0; }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) d = max(d, __shfl_xor(d, o));
   if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(depthOut, d);
@@ -253,7 +254,7 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
     k_karras<<<grid_for(ni), kBlock, 0, stream>>>(n, keysSorted, left, right, first, last, parentI, parentL);
     k_fit<<<grid_for(n), kBlock, 0, stream>>>(n, left, right, parentI, parentL, leafLo, leafHi, ilo, ihi, arrivals);
     k_opened<<<grid_for(ni), kBlock, 0, stream>>>(ni, left, right, first, last, leafSize, ilo, ihi, opened);
-    k_kept<<<grid_for(ni), kBlock, 0, stream>>>(ni, first, last, parentI, leafSize, opened, kept, dDepth);
+    k_kept<<<(ni + 63) / 64, 64, 0, stream>>>(ni, first, last, parentI, leafSize, opened, kept, dDepth);
     LB_CHECK(rocprim::exclusive_scan(tmp, tmpScan, kept, newIndex, 0, (size_t)ni, rocprim::plus<int>(), stream));
     LB_CHECK(hipMemcpyAsync(&hostCount[0], newIndex + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
     LB_CHECK(hipMemcpyAsync(&hostCount[1], kept + (ni - 1), sizeof(int), hipMemcpyDeviceToHost, stream));

@@ -144,17 +144,20 @@ PT_HD int wide_children(int r, const int* left, const int* right, const int* fir
 // communication between nodes, same answer on every run.  opened[2*r], opened[2*r+1] hold the nodes that r would
 // absorb as a wide node (wide_children, computed once per surviving node).  Keys are 64 bits, so a path has at
 // most 64 nodes.
-PT_HD int wide_level(int i, const int* first, const int* last, const int* parentI, int leafSize, const int* opened) {
+// path: caller-provided storage for kMaxKarrasPath ints with the given stride (LDS column on the device).
+constexpr int kMaxKarrasPath = 66;
+PT_HD int wide_level(int i, const int* first, const int* last, const int* parentI, int leafSize, const int* opened,
+                     int* path, int stride) {
   if (!karras_kept(i, first, last, leafSize)) return 0;
-  int path[66]; int np = 0;
-  for (int p = i; p >= 0 && np < 66; p = parentI[p]) path[np++] = p;
+  int np = 0;
+  for (int p = i; p >= 0 && np < kMaxKarrasPath; p = parentI[p]) path[(np++) * stride] = p;
   int k = np - 1, level = 1;
   for (;;) {
-    const int cur = path[k];
+    const int cur = path[k * stride];
     if (cur == i) return level;
     const int op0 = opened[2 * (size_t)cur], op1 = opened[2 * (size_t)cur + 1];
     k--;
-    while (path[k] == op0 || path[k] == op1) { if (path[k] == i) return 0; k--; }
+    while (path[k * stride] == op0 || path[k * stride] == op1) { if (path[k * stride] == i) return 0; k--; }
     level++;
   }
 }

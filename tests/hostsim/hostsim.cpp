@@ -193,8 +193,9 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
       wide_children(i, left.data(), right.data(), first.data(), last.data(), leafSize, iloF, ihiF, ch, op);
     openedBy[2 * (size_t)i] = op[0]; openedBy[2 * (size_t)i + 1] = op[1];
   }
+  int pathBuf[kMaxKarrasPath];
   for (int i = 0; i < ni; i++)
-    if (wide_level(i, first.data(), last.data(), parentI.data(), leafSize, openedBy.data()) > 0) newIndex[i] = nKept++;
+    if (wide_level(i, first.data(), last.data(), parentI.data(), leafSize, openedBy.data(), pathBuf, 1) > 0) newIndex[i] = nKept++;
   out.nodes.resize(nKept);
   auto box_of = [&](int child, v3& blo, v3& bhi) {
     if (child < 0) { blo = llo[~child]; bhi = lhi[~child]; } else { blo = ilo[child]; bhi = ihi[child]; }
