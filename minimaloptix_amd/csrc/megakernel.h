@@ -25,7 +25,12 @@ struct LaunchArgs {
   // variant 2 (queuekernel.hip)
   int swapLanes;                    // leave the node loop once this many lanes stand at a leaf / have finished
   int ovfDepth;                     // ints of stack overflow per slot
+  // XCD-aware work distribution (queuekernel.hip): the rank's tiles are cut into kWorkGroups contiguous bands,
+  // workCounter[2 + g] hands out the (sample, slot) items of band g; a workgroup starts in the band of its XCD
+  int xcdBands;                     // 0 = one global counter, 1 = per-XCD bands
+  int bandTiles;                    // tiles per band (the last band may be shorter)
 };
+constexpr int kWorkGroups = 8;      // = XCDs of an MI355X
 
 #if defined(__HIPCC__)
 // work item k -> (sample index, pixel).  Slot i = k % nItems is the (i & 63)-th pixel of this
@@ -40,6 +45,22 @@ __device__ __forceinline__ bool item_to_pixel(const LaunchArgs& a, int k, int& s
   const int x = tx * 8 + (in & 7), y = ty * 8 + (in >> 3);
   pixel = y * a.scene.width + x;
   return (x < a.scene.width) & (y < a.scene.height);
+}
+// Band g's j-th item -> canonical work item k (the index item_to_pixel / the per-sample buffer use), or -1 past
+// the band's end.  Items of a band run sample-major inside the band.
+__device__ __forceinline__ int band_item(const LaunchArgs& a, int g, int j) {
+  const int t0 = g * a.bandTiles, nTiles = a.nItems >> 6;
+  const int t1 = min(t0 + a.bandTiles, nTiles);
+  if (t1 <= t0) return -1;
+  const int ips = (t1 - t0) << 6;                      // items per sample in this band
+  const int sample = j / ips;
+  if (sample >= a.nSeeds) return -1;
+  return sample * a.nItems + (t0 << 6) + (j - sample * ips);
+}
+__device__ __forceinline__ int xcc_id() {
+  int v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xf;
 }
 // Camera.cu:39 result of one sample; Camera.cu:41 (the add) happens in k_reduce_samples
 __device__ __forceinline__ void store_sample(const LaunchArgs& a, int item, v3 value) {

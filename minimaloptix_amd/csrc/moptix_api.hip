@@ -71,6 +71,7 @@ struct moptix_context_t {
 
   int rank = 0, nRanks = 1;
   int optExitThreshold = 16, optLeafSize = 4, optBlocksPerCU = 3, optVariant = 3;
+  int optXcdBands = 0;   // measured: 208.3 ms with bands vs 206.9 ms without (coffee 64 spp) -- off
   int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 8192, optLeafThreshold = 16, optSwapLanes = 24;
   unsigned long long lastExtra[5] = { 0, 0, 0, 0, 0 };
 
@@ -205,7 +206,9 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   }
   HIPCHK(c, c->dSampleBuf.ensure((size_t)perPass * a.nItems * 3), "alloc per-sample buffer");
   a.sampleBuf = c->dSampleBuf.p;
-  HIPCHK(c, c->dWork.ensure(2), "alloc work counter");   // [0] work counter, [1] watchdog flag
+  HIPCHK(c, c->dWork.ensure(2 + kWorkGroups), "alloc work counter");   // [0] work counter, [1] watchdog flag, [2..] per-band counters
+  a.xcdBands = (useQueue && c->optXcdBands) ? 1 : 0;
+  a.bandTiles = (int)((localTiles + kWorkGroups - 1) / kWorkGroups);
   a.workCounter = c->dWork.p;
   if (counted) {
     HIPCHK(c, c->dCounters.ensure(40), "alloc counters");
@@ -218,7 +221,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   for (long long first = 0; first < nSeeds; first += perPass) {
     const int n = (int)std::min(perPass, (long long)nSeeds - first);
     a.seeds = c->dSeeds.p + first; a.nSeeds = n; a.nWork = n * a.nItems;
-    HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, 2 * sizeof(int), c->stream), "zero work counter");
+    HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, (2 + kWorkGroups) * sizeof(int), c->stream), "zero work counters");
     HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
     if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, c->optVariant == 3, counted), "launch queue megakernel");
     else if (usePool) HIPCHK(c, launch_poolkernel(c->stream, a, nBlocks, c->optPoolSlots, counted), "launch pool megakernel");
@@ -514,6 +517,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "swap_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "swap_lanes in [1,64]"); c->optSwapLanes = value; }
   else if (!strcmp(name, "refill_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "refill_lanes in [1,64]"); c->optRefillLanes = value; }
   else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
+  else if (!strcmp(name, "xcd_bands")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "xcd_bands in {0,1}"); c->optXcdBands = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
 }
@@ -530,6 +534,7 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "swap_lanes")) *value = c->optSwapLanes;
   else if (!strcmp(name, "refill_lanes")) *value = c->optRefillLanes;
   else if (!strcmp(name, "starve_lanes")) *value = c->optStarveLanes;
+  else if (!strcmp(name, "xcd_bands")) *value = c->optXcdBands;
   else if (!strcmp(name, "num_cus")) *value = c->numCUs;
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;

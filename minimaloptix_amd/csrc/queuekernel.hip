@@ -247,6 +247,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
 
   // result of the last pass, queued inside the next transaction
   int pendSlot = -1, pendDest = DEST_NONE;
+  // work distribution: band of this XCD, bands found empty so far (per lane)
+  const int myBand = a.xcdBands ? (xcc_id() & (kWorkGroups - 1)) : 0;
+  int bandOfs = 0;
 
   // ---- leaf pass: the slots popped from Q_LEAF stand at a leaf ----
   auto leaf_pass = [&](int slot) {
@@ -328,9 +331,29 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         } else if (ps.mode == M_LIGHTS) {
           on_lights<CNT>(sc, ps, ct);
         } else {  // M_NEW_PIXEL: next (pixel, sample) work item
-          const int k = atomicAdd(a.workCounter, 1);
+          int k = -1;
+          if (a.xcdBands) {
+            // this workgroup's XCD works through its own band of the image first (its L2 then sees one
+            // region's nodes and triangles), then helps with the bands that still have items
+            // one atomic per wave and band: the lanes asking for the same band reserve a run of items together
+            while (k < 0 && bandOfs < kWorkGroups) {
+              const int g = (myBand + bandOfs) & (kWorkGroups - 1);
+              if (g == __builtin_amdgcn_readfirstlane(g)) {
+                const unsigned long long m = __ballot(true);
+                const int leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(a.workCounter + 2 + g, __popcll(m));
+                base = __shfl(base, leader);
+                k = band_item(a, g, base + lane_rank(m));
+                if (k < 0) bandOfs++;
+              }
+            }
+          } else {
+            k = atomicAdd(a.workCounter, 1);
+            if (k >= a.nWork) k = -1;
+          }
           int s;
-          if (k >= a.nWork) { ps.mode = M_DONE; }
+          if (k < 0) { ps.mode = M_DONE; }
           else if (item_to_pixel(a, k, s, ps.pixel)) { ps.item = k; begin_sample<CNT>(sc, ps, a.seeds[s], ct); }
         }
       }
