@@ -25,12 +25,12 @@ struct LaunchArgs {
   // variant 2 (queuekernel.hip)
   int swapLanes;                    // leave the node loop once this many lanes stand at a leaf / have finished
   int ovfDepth;                     // ints of stack overflow per slot
-  // XCD-aware work distribution (queuekernel.hip): the rank's tiles are cut into kWorkGroups contiguous bands,
-  // workCounter[2 + g] hands out the (sample, slot) items of band g; a workgroup starts in the band of its XCD
-  int xcdBands;                     // 0 = one global counter, 1 = per-XCD bands
-  int bandTiles;                    // tiles per band (the last band may be shorter)
+  // hand-out order of the work items (queuekernel.hip): tile-major, tiles with the deepest paths first
+  int tileMajor;                    // 0 = sample-major in raster tile order (item k handed out as k)
+  const int* tileOrder;             // local tile visited i-th (device, nItems/64 entries) or nullptr = raster order
+  unsigned int* tileCost;           // per local tile: deepest path seen so far (device) or nullptr
 };
-constexpr int kWorkGroups = 8;      // = XCDs of an MI355X
+constexpr int kDeepPath = 8;        // paths at least this deep are recorded in tileCost
 
 #if defined(__HIPCC__)
 // work item k -> (sample index, pixel).  Slot i = k % nItems is the (i & 63)-th pixel of this
@@ -46,21 +46,19 @@ __device__ __forceinline__ bool item_to_pixel(const LaunchArgs& a, int k, int& s
   pixel = y * a.scene.width + x;
   return (x < a.scene.width) & (y < a.scene.height);
 }
-// Band g's j-th item -> canonical work item k (the index item_to_pixel / the per-sample buffer use), or -1 past
-// the band's end.  Items of a band run sample-major inside the band.
-__device__ __forceinline__ int band_item(const LaunchArgs& a, int g, int j) {
-  const int t0 = g * a.bandTiles, nTiles = a.nItems >> 6;
-  const int t1 = min(t0 + a.bandTiles, nTiles);
-  if (t1 <= t0) return -1;
-  const int ips = (t1 - t0) << 6;                      // items per sample in this band
-  const int sample = j / ips;
-  if (sample >= a.nSeeds) return -1;
-  return sample * a.nItems + (t0 << 6) + (j - sample * ips);
-}
-__device__ __forceinline__ int xcc_id() {
-  int v;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-  return v & 0xf;
+// Hand-out index k -> canonical work item (the index item_to_pixel and the per-sample buffer use).  Tile-major:
+// all samples of a tile are handed out back to back, tile after tile in tileOrder; the paths that bounce 256 times
+// (a chain of ~1000 dependent rays, ~28 ms) then start early and overlap the bulk instead of forming the tail.
+__device__ __forceinline__ int handout_to_item(const LaunchArgs& a, int k) {
+  if (!a.tileMajor) return k;
+  const int per = a.nSeeds << 6;                       // items of one tile
+  const int ti = k / per, r = k - ti * per;
+  const int lt = a.tileOrder ? a.tileOrder[ti] : ti;
+  if (a.tileMajor == 2) {                               // experiment: consecutive items = samples of ONE pixel
+    const int in = r / a.nSeeds, sample = r - in * a.nSeeds;
+    return sample * a.nItems + (lt << 6) + in;
+  }
+  return (r >> 6) * a.nItems + (lt << 6) + (r & 63);
 }
 // Camera.cu:39 result of one sample; Camera.cu:41 (the add) happens in k_reduce_samples
 __device__ __forceinline__ void store_sample(const LaunchArgs& a, int item, v3 value) {

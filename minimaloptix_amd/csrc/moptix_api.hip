@@ -2,6 +2,7 @@
 // Host-side staging of the scene, upload, LBVH build, launches, read-back, measurement.
 // There is no CPU path: every entry point that computes needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -71,7 +72,9 @@ struct moptix_context_t {
 
   int rank = 0, nRanks = 1;
   int optExitThreshold = 16, optLeafSize = 4, optBlocksPerCU = 3, optVariant = 3;
-  int optXcdBands = 0;   // measured: 208.3 ms with bands vs 206.9 ms without (coffee 64 spp) -- off
+  int optTileMajor = 1;
+  long long tileHistoryTiles = -1;
+  DevBuf<unsigned int> dTileCost, dTileCostSorted; DevBuf<int> dTileOrder, dTileIota; DevBuf<uint8_t> dSortTmp;
   int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 8192, optLeafThreshold = 16, optSwapLanes = 24;
   unsigned long long lastExtra[5] = { 0, 0, 0, 0, 0 };
 
@@ -145,6 +148,7 @@ int read_stats(moptix_context c, moptix_stats* stats) {
     if (h[32]) fprintf(stderr, "[moptix] swap detail: local %.1f%% lock-wait %.1f%% txn %.1f%% idle %.1f%% | batch detail: load %.1f%% run %.1f%% store %.1f%% | "
                        "iterations %llu transactions %llu (cycles/iter %.0f)\n", 100 * h[24] / tt, 100 * h[25] / tt, 100 * h[26] / tt, 100 * h[27] / tt,
                        100 * h[28] / tt, 100 * h[29] / tt, 100 * h[30] / tt, h[32], h[31], tt / (double)h[32]);
+    if (h[32]) fprintf(stderr, "[moptix] batch iterations executing on_result %llu, on_lights %llu, new item %llu (batches %llu)\n", h[33], h[34], h[35], h[11]);
     if (h[22]) fprintf(stderr, "[moptix] node steps %llu (%.1f lanes avg), leaf passes %llu (%.1f lanes avg)\n", h[9] - h[22],
             (double)(h[10] - h[23]) / (double)(h[9] - h[22]), h[22], (double)h[23] / (double)h[22]);
   }
@@ -206,9 +210,27 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   }
   HIPCHK(c, c->dSampleBuf.ensure((size_t)perPass * a.nItems * 3), "alloc per-sample buffer");
   a.sampleBuf = c->dSampleBuf.p;
-  HIPCHK(c, c->dWork.ensure(2 + kWorkGroups), "alloc work counter");   // [0] work counter, [1] watchdog flag, [2..] per-band counters
-  a.xcdBands = (useQueue && c->optXcdBands) ? 1 : 0;
-  a.bandTiles = (int)((localTiles + kWorkGroups - 1) / kWorkGroups);
+  HIPCHK(c, c->dWork.ensure(2), "alloc work counter");   // [0] work counter, [1] watchdog flag
+  a.tileMajor = useQueue ? c->optTileMajor : 0;
+  a.tileOrder = nullptr; a.tileCost = nullptr;
+  if (a.tileMajor) {
+    if (c->tileHistoryTiles != localTiles) {             // new frame size / partition: forget the history
+      HIPCHK(c, c->dTileCost.ensure((size_t)localTiles), "alloc tile cost");
+      HIPCHK(c, c->dTileCostSorted.ensure((size_t)localTiles), "alloc tile cost");
+      HIPCHK(c, c->dTileOrder.ensure((size_t)localTiles), "alloc tile order");
+      std::vector<int> iota((size_t)localTiles);
+      for (size_t i = 0; i < iota.size(); i++) iota[i] = (int)i;
+      HIPCHK(c, c->dTileIota.upload(iota, c->stream), "upload tile ids");
+      HIPCHK(c, hipMemsetAsync(c->dTileCost.p, 0, sizeof(unsigned int) * (size_t)localTiles, c->stream), "zero tile cost");
+      size_t tmpBytes = 0;
+      HIPCHK(c, rocprim::radix_sort_pairs_desc(nullptr, tmpBytes, c->dTileCost.p, c->dTileCostSorted.p, c->dTileIota.p, c->dTileOrder.p,
+                                               (size_t)localTiles, 0, 32, c->stream), "size tile sort");
+      HIPCHK(c, c->dSortTmp.ensure(tmpBytes), "alloc sort scratch");
+      HIPCHK(c, hipStreamSynchronize(c->stream), "sync tile history");    // iota staging dies here
+      c->tileHistoryTiles = localTiles;
+    }
+    a.tileOrder = c->dTileOrder.p; a.tileCost = c->dTileCost.p;
+  }
   a.workCounter = c->dWork.p;
   if (counted) {
     HIPCHK(c, c->dCounters.ensure(40), "alloc counters");
@@ -221,7 +243,13 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   for (long long first = 0; first < nSeeds; first += perPass) {
     const int n = (int)std::min(perPass, (long long)nSeeds - first);
     a.seeds = c->dSeeds.p + first; a.nSeeds = n; a.nWork = n * a.nItems;
-    HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, (2 + kWorkGroups) * sizeof(int), c->stream), "zero work counters");
+    HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, 2 * sizeof(int), c->stream), "zero work counter");
+    if (a.tileMajor && a.tileCost) {
+      // tiles in descending order of the deepest path seen so far (stable: ties stay in raster order)
+      size_t tmpBytes = c->dSortTmp.n;
+      HIPCHK(c, rocprim::radix_sort_pairs_desc(c->dSortTmp.p, tmpBytes, c->dTileCost.p, c->dTileCostSorted.p, c->dTileIota.p, c->dTileOrder.p,
+                                               (size_t)localTiles, 0, 32, c->stream), "sort tiles");
+    }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
     if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, c->optVariant == 3, counted), "launch queue megakernel");
     else if (usePool) HIPCHK(c, launch_poolkernel(c->stream, a, nBlocks, c->optPoolSlots, counted), "launch pool megakernel");
@@ -278,6 +306,7 @@ int moptix_destroy(moptix_context c) {
   c->dFaceUV.release(); c->dTexels.release(); c->dTextures.release();
   lbvh_free(&c->bvh);
   c->dPoolCold.release(); c->dSampleBuf.release();
+  c->dTileCost.release(); c->dTileCostSorted.release(); c->dTileOrder.release(); c->dTileIota.release(); c->dSortTmp.release();
   c->dAccum.release(); c->dSeeds.release(); c->dWork.release(); c->dCounters.release(); c->dOverflow.release(); c->dRgb8.release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -454,6 +483,7 @@ int moptix_build_accel(moptix_context c, const char* kind) {
   }
   HIPCHK(c, hipStreamSynchronize(c->stream), "sync after upload");
   c->sceneDirty = false; c->accelBuilt = true;
+  c->tileHistoryTiles = -1;            // new scene: forget which tiles had deep paths
   return MOPTIX_OK;
 }
 
@@ -517,7 +547,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "swap_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "swap_lanes in [1,64]"); c->optSwapLanes = value; }
   else if (!strcmp(name, "refill_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "refill_lanes in [1,64]"); c->optRefillLanes = value; }
   else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
-  else if (!strcmp(name, "xcd_bands")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "xcd_bands in {0,1}"); c->optXcdBands = value; }
+  else if (!strcmp(name, "tile_major")) { if (value < 0 || value > 2) return fail(c, MOPTIX_ERR_INVALID, "tile_major in {0,1,2}"); c->optTileMajor = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
 }
@@ -534,7 +564,7 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "swap_lanes")) *value = c->optSwapLanes;
   else if (!strcmp(name, "refill_lanes")) *value = c->optRefillLanes;
   else if (!strcmp(name, "starve_lanes")) *value = c->optStarveLanes;
-  else if (!strcmp(name, "xcd_bands")) *value = c->optXcdBands;
+  else if (!strcmp(name, "tile_major")) *value = c->optTileMajor;
   else if (!strcmp(name, "num_cus")) *value = c->numCUs;
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;

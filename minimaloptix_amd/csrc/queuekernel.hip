@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
 
   // sub-phase clocks of the counting build
   unsigned long long tLocal = 0, tLock = 0, tTxn = 0, tIdle = 0, tBLoad = 0, tBRun = 0, tBStore = 0, nTxn = 0, nIter = 0;
-  unsigned long long tSub = 0;
+  unsigned long long tSub = 0, nIterResult = 0, nIterLights = 0, nIterGen = 0;
 #define PT_SUB0() do { if (CNT) tSub = __builtin_amdgcn_s_memtime(); } while (0)
 #define PT_SUB(acc) do { if (CNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tSub; tSub = now_; } } while (0)
   // queue bookkeeping: registers (wave-uniform); with SHARED they mirror LDS inside a transaction
@@ -247,9 +247,6 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
 
   // result of the last pass, queued inside the next transaction
   int pendSlot = -1, pendDest = DEST_NONE;
-  // work distribution: band of this XCD, bands found empty so far (per lane)
-  const int myBand = a.xcdBands ? (xcc_id() & (kWorkGroups - 1)) : 0;
-  int bandOfs = 0;
 
   // ---- leaf pass: the slots popped from Q_LEAF stand at a leaf ----
   auto leaf_pass = [&](int slot) {
@@ -322,36 +319,30 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     }
     if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBLoad); }
     for (;;) {
-      if (have && ps.mode == M_NEW_SAMPLE) { store_sample(a, ps.item, ps.accum); ps.mode = M_NEW_PIXEL; }
-      const bool run = have && ps.mode != M_TRACE && ps.mode != M_DONE && !(shadeBatch && ps.mode == M_NEW_PIXEL);
+      if (have && ps.mode == M_NEW_SAMPLE) {
+        store_sample(a, ps.item, ps.accum);
+        if (a.tileCost != nullptr && ps.depth >= kDeepPath) atomicMax(a.tileCost + ((ps.item % a.nItems) >> 6), (unsigned int)ps.depth);
+        ps.mode = M_NEW_PIXEL;
+      }
+      // lanes that arrive with a finished ray go first; the lanes that only need a new work item wait for them, so
+      // that begin_sample + the ray set-up run once, for all of them together
+      const bool resultFirst = __ballot(have && ps.mode == M_RESULT) != 0ull;
+      const bool run = have && ps.mode != M_TRACE && ps.mode != M_DONE &&
+                       !((shadeBatch || resultFirst) && ps.mode == M_NEW_PIXEL);
       if (__ballot(run) == 0ull) break;
+      if (CNT) {   // which state-machine stages this iteration executes (wave level)
+        if (__ballot(run && ps.mode == M_RESULT)) nIterResult++;
+        if (__ballot(run && ps.mode == M_LIGHTS)) nIterLights++;
+        if (__ballot(run && ps.mode == M_NEW_PIXEL)) nIterGen++;
+      }
       if (run) {
         if (ps.mode == M_RESULT) {
           on_result<CNT>(sc, ps, res, ct);
         } else if (ps.mode == M_LIGHTS) {
           on_lights<CNT>(sc, ps, ct);
         } else {  // M_NEW_PIXEL: next (pixel, sample) work item
-          int k = -1;
-          if (a.xcdBands) {
-            // this workgroup's XCD works through its own band of the image first (its L2 then sees one
-            // region's nodes and triangles), then helps with the bands that still have items
-            // one atomic per wave and band: the lanes asking for the same band reserve a run of items together
-            while (k < 0 && bandOfs < kWorkGroups) {
-              const int g = (myBand + bandOfs) & (kWorkGroups - 1);
-              if (g == __builtin_amdgcn_readfirstlane(g)) {
-                const unsigned long long m = __ballot(true);
-                const int leader = __ffsll((long long)m) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(a.workCounter + 2 + g, __popcll(m));
-                base = __shfl(base, leader);
-                k = band_item(a, g, base + lane_rank(m));
-                if (k < 0) bandOfs++;
-              }
-            }
-          } else {
-            k = atomicAdd(a.workCounter, 1);
-            if (k >= a.nWork) k = -1;
-          }
+          int k = atomicAdd(a.workCounter, 1);
+          k = (k >= a.nWork) ? -1 : handout_to_item(a, k);
           int s;
           if (k < 0) { ps.mode = M_DONE; }
           else if (item_to_pixel(a, k, s, ps.pixel)) { ps.item = k; begin_sample<CNT>(sc, ps, a.seeds[s], ct); }
@@ -536,6 +527,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       atomicAdd(&c[21], __builtin_amdgcn_s_memtime() - tStart);
       atomicAdd(&c[22], (unsigned long long)leafPasses); atomicAdd(&c[23], (unsigned long long)leafLanes);
       atomicAdd(&c[24], tLocal); atomicAdd(&c[25], tLock); atomicAdd(&c[26], tTxn); atomicAdd(&c[27], tIdle);
+      atomicAdd(&c[33], nIterResult); atomicAdd(&c[34], nIterLights); atomicAdd(&c[35], nIterGen);
       atomicAdd(&c[28], tBLoad); atomicAdd(&c[29], tBRun); atomicAdd(&c[30], tBStore); atomicAdd(&c[31], nTxn); atomicAdd(&c[32], nIter);
     }
   }
