@@ -531,6 +531,7 @@ int moptix_sync(moptix_context c) {
 
 int moptix_set_partition(moptix_context c, int32_t rank, int32_t nRanks) {
   if (!c || nRanks < 1 || rank < 0 || rank >= nRanks) return fail(c, MOPTIX_ERR_INVALID, "bad partition");
+  if (rank != c->rank || nRanks != c->nRanks) c->tileHistoryTiles = -1;   // other tiles: the deep-path history does not apply
   c->rank = rank; c->nRanks = nRanks;
   return MOPTIX_OK;
 }
