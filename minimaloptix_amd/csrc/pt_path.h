@@ -199,25 +199,36 @@ PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, St
   }
 }
 
-// One leaf (count x 48-byte triangle records) for a lane with tv.node < 0.
+// One leaf (count x 48-byte triangle records) for a lane with tv.node < 0.  The records of up to four
+// triangles are fetched together (one memory round trip per chunk instead of one per triangle; slots past the
+// end of the leaf re-read its last record, which costs no extra line) and then tested in order.
 template <bool CNT, class Stack>
 PT_HD void trav_leaf_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
   {
     const int first = leaf_first(tv.node), count = leaf_count(tv.node);
     const int triBase = sc.nSpheres + sc.nQuads;
     bool terminated = false;
-    for (int k = 0; k < count; k++) {
-      const Tri48* tp = sc.tris + (first + k);
-      const v3 p0 = tp->p0, e0 = tp->e0, e1 = tp->e1;
-      const int mat = tp->mat, prim = tp->prim;
-      cnt<CNT>(ct.triTests);
-      v3 n; float t, be, ga;
-      if (tri_test(ps.o, ps.d, ps.tmin, ps.tmax, p0, e0, e1, n, t, be, ga)) {     // meshIntersect, Geometry.cu:121-160
-        if (ps.kind == RK_RADIANCE) {
-          if (potential(t, triBase + prim, ps.tmin, tv.tbest, tv.bestPrim)) {
-            tv.tbest = t; tv.bestPrim = triBase + prim; tv.bestTri = first + k; tv.beta = be; tv.gamma = ga;
+    for (int base = 0; base < count && !terminated; base += 4) {
+      v3 p0[4], e0[4], e1[4]; int mat[4], prim[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = base + j < count ? base + j : count - 1;
+        const Tri48* tp = sc.tris + (first + k);
+        p0[j] = tp->p0; e0[j] = tp->e0; e1[j] = tp->e1; mat[j] = tp->mat; prim[j] = tp->prim;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (base + j < count && !terminated) {
+          cnt<CNT>(ct.triTests);
+          v3 n; float t, be, ga;
+          if (tri_test(ps.o, ps.d, ps.tmin, ps.tmax, p0[j], e0[j], e1[j], n, t, be, ga)) {   // meshIntersect, Geometry.cu:121-160
+            if (ps.kind == RK_RADIANCE) {
+              if (potential(t, triBase + prim[j], ps.tmin, tv.tbest, tv.bestPrim)) {
+                tv.tbest = t; tv.bestPrim = triBase + prim[j]; tv.bestTri = first + base + j; tv.beta = be; tv.gamma = ga;
+              }
+            } else if (shadow_any_hit(sc, mat[j], tv.att)) terminated = true;
           }
-        } else if (shadow_any_hit(sc, mat, tv.att)) { terminated = true; break; }
+        }
       }
     }
     if (terminated) tv.node = kTravDone;
@@ -312,7 +323,10 @@ PT_HD void hit_attributes(const SceneView& sc, const PathState& ps, const Trav& 
   } else {
     const Tri48* tp = sc.tris + tv.bestTri;
     const TriShade* sp = sc.triShade + tv.bestTri;
+    // both records are requested before either is used: one memory round trip, not two
     const v3 p0 = tp->p0, e0 = tp->e0, e1 = tp->e1;
+    const v3 sn0 = sp->n0, sn1 = sp->n1, sn2 = sp->n2;
+    const int hasNormals = sp->hasNormals;
     h.mat = tp->mat;
     h.texu = 0.f; h.texv = 0.f;
     if (sc.triUV != nullptr && sc.mats[h.mat].albedoTex != 0) {               // Geometry.cu:141-148
@@ -324,8 +338,8 @@ PT_HD void hit_attributes(const SceneView& sc, const PathState& ps, const Trav& 
       }
     }
     h.geoNormal = normalize(cross(e1, e0));
-    if (sp->hasNormals) {
-      const v3 n0 = sp->n0, n1 = sp->n1, n2 = sp->n2;
+    if (hasNormals) {
+      const v3 n0 = sn0, n1 = sn1, n2 = sn2;
       h.shadingNormal = normalize((n1 * tv.beta + n2 * tv.gamma) + n0 * (1.f - tv.beta - tv.gamma));
     } else {
       h.shadingNormal = h.geoNormal;
