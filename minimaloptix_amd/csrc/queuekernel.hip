@@ -33,9 +33,19 @@ namespace {
 
 constexpr int kBlockThreads = 256;
 constexpr int kWaves = kBlockThreads / 64;
-constexpr int kP = 128;                 // slots per wave
-constexpr int kStackN = 11;             // LDS stack entries per slot; deeper levels spill to HBM
-constexpr int kWavesPerSimd = 3;        // occupancy target: 3 workgroups per CU (VGPR <= 168, LDS <= 53 KB)
+#ifndef PT_KP
+#define PT_KP 128
+#endif
+#ifndef PT_STACKN
+#define PT_STACKN 11
+#endif
+#ifndef PT_WAVES_PER_SIMD
+#define PT_WAVES_PER_SIMD 3
+#endif
+constexpr int kP = PT_KP;               // slots per wave
+constexpr int kStackN = PT_STACKN;      // LDS stack entries per slot; deeper levels spill to HBM
+constexpr int kWavesPerSimd = PT_WAVES_PER_SIMD;   // occupancy target: 3 workgroups per CU (VGPR <= 168, LDS <= 53 KB)
+constexpr int ring_capacity(int n) { int c = 1; while (c < n) c <<= 1; return c; }
 
 // pool-wide queues first (they index PoolLds::queue); Q_NODE / Q_LEAF are per-wave rings (WavePriv)
 enum { Q_SHADE = 0, Q_GEN = 1, kNumQ = 2, Q_NODE = 2, Q_LEAF = 3, DEST_DONE = 4, DEST_NONE = -1 };
@@ -93,14 +103,14 @@ struct PoolLds {
   v4 nodeA[NS];           // o.xyz, tbest
   v4 nodeB[NS];           // 1/d, node (int bits)
   int stack[NS][kStackN + 1];   // [0] = sp | kShadeFlag, [1..] = entries
-  unsigned short queue[kNumQ][NS];
+  unsigned short queue[kNumQ][ring_capacity(NS)];
   int qHead[kNumQ], qCount[kNumQ];   // SHARED only
   int done, lock;                    // SHARED only
 };
 
 template <int NS>
 struct WavePriv {
-  unsigned short qnode[NS];        // node-ready slots owned by this wave (ring)
+  unsigned short qnode[ring_capacity(NS)];   // node-ready slots owned by this wave (ring)
   // One loop iteration pushes at most 128 slots (results of the last pass + lanes leaving the node loop).
   unsigned short qleaf[256];       // slots standing at a leaf, owned by this wave (ring; a pass runs at 64: < 64 + 128)
   unsigned short outbox[2][160];   // slots on their way to the pool's Q_SHADE / Q_GEN (flushed at 32: < 32 + 128)
@@ -144,6 +154,7 @@ __device__ __forceinline__ int route(int node, int kind, int bestPrim) {
 template <bool CNT, bool SHARED>
 __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(const LaunchArgs a) {
   constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
+  constexpr int RC = ring_capacity(NS);                  // ring capacity (power of two >= NS)
   __shared__ PoolLds<NS> sPool[SHARED ? 1 : kWaves];
   __shared__ WavePriv<NS> sPriv[kWaves];
 
@@ -166,15 +177,15 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
   [[maybe_unused]] auto q_push = [&](int q, bool pred, int slot) {
     const unsigned long long m = __ballot(pred);
     if (m == 0ull) return;
-    if (pred) W.queue[q][(qHead[q] + qCount[q] + lane_rank(m)) & (NS - 1)] = (unsigned short)slot;
+    if (pred) W.queue[q][(qHead[q] + qCount[q] + lane_rank(m)) & (RC - 1)] = (unsigned short)slot;
     qCount[q] += __popcll(m);
   };
   auto q_pop = [&](int q, bool want) -> int {
     const unsigned long long m = __ballot(want);
     const int n = min(__popcll(m), qCount[q]);
     int slot = -1;
-    if (want) { const int r = lane_rank(m); if (r < n) slot = W.queue[q][(qHead[q] + r) & (NS - 1)]; }
-    qHead[q] = (qHead[q] + n) & (NS - 1);
+    if (want) { const int r = lane_rank(m); if (r < n) slot = W.queue[q][(qHead[q] + r) & (RC - 1)]; }
+    qHead[q] = (qHead[q] + n) & (RC - 1);
     qCount[q] -= n;
     return slot;
   };
@@ -393,7 +404,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     {
       const unsigned long long m = __ballot(dest == Q_NODE);
       if (m != 0ull) {
-        if (dest == Q_NODE) myNodeQ[(nqHead + nqCount + lane_rank(m)) & (NS - 1)] = (unsigned short)slot;
+        if (dest == Q_NODE) myNodeQ[(nqHead + nqCount + lane_rank(m)) & (RC - 1)] = (unsigned short)slot;
         nqCount += __popcll(m);
       }
     }
@@ -437,7 +448,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         if (ns < 0) {
           const int r = lane_rank(m);
           if (r < n) {
-            ns = myNodeQ[(nqHead + r) & (NS - 1)];
+            ns = myNodeQ[(nqHead + r) & (RC - 1)];
             const v4 na = W.nodeA[ns], nb = W.nodeB[ns];
             const int spw = W.stack[ns][0];
             nray.o = mk3(na.x, na.y, na.z); ntv.tbest = na.w;
@@ -446,7 +457,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
             ntv.sp = spw & ~kShadeFlag; nsFlag = spw & kShadeFlag;
           }
         }
-        nqHead = (nqHead + n) & (NS - 1); nqCount -= n;
+        nqHead = (nqHead + n) & (RC - 1); nqCount -= n;
       }
     }
     const int nActive = __popcll(__ballot(ns >= 0));
@@ -471,7 +482,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         const int q = Q_SHADE + d;
         for (int base = 0; base < obCount[d]; base += 64) {
           const int i = base + lane;
-          if (i < obCount[d]) W.queue[q][(qHead[q] + qCount[q] + i) & (NS - 1)] = sPriv[wave].outbox[d][i];
+          if (i < obCount[d]) W.queue[q][(qHead[q] + qCount[q] + i) & (RC - 1)] = sPriv[wave].outbox[d][i];
         }
         qCount[q] += obCount[d]; obCount[d] = 0;
       }
