@@ -21,7 +21,7 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -mavx2 -mfma 
 DEV_SRCS := $(CSRC)/moptix_api.hip $(CSRC)/megakernel.hip $(CSRC)/poolkernel.hip $(CSRC)/queuekernel.hip $(CSRC)/lbvh.hip
 DEV_OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(DEV_SRCS))
 DEV_HDRS := $(wildcard $(CSRC)/*.h) include/moptix.h
-HOST_SRCS := $(HOST)/obj_loader.cpp $(HOST)/scene_file.cpp $(HOST)/scenes.cpp $(HOST)/standin_scenes.cpp $(HOST)/image_read.cpp \
+HOST_SRCS := $(HOST)/obj_loader.cpp $(HOST)/scene_file.cpp $(HOST)/scenes.cpp $(HOST)/standin_scenes.cpp $(HOST)/image_read.cpp $(HOST)/jpeg_read.cpp \
              $(HOST)/image_io.cpp $(HOST)/minimal_optix.cpp $(HOST)/host_capi.cpp
 HOST_OBJS := $(patsubst $(HOST)/%.cpp,build/host_%.o,$(HOST_SRCS))
 HOST_HDRS := $(wildcard $(HOST)/*.h) $(wildcard $(CSRC)/pt_*.h) include/moptix.h include/moptix_host.h

@@ -48,7 +48,7 @@ int mohost_scene_copy_texcoords(mohost_scene s, float* texcoords, int32_t* tIdx)
 /* texture i (< nTextures; DisneyParams.albedoID - 1): size and, if rgba != NULL, its 4*w*h floats as uploaded
  * (MinimalOptiX.cpp:459-472: row 0 = bottom image row, alpha 1) */
 int mohost_scene_texture(mohost_scene s, int32_t i, int32_t* width, int32_t* height, float* rgba);
-/* QImage(path) stand-in used for albedoTex files: PNG (non-interlaced) and binary PNM -> 8-bit RGB, row 0 = top.
+/* QImage(path) stand-in used for albedoTex files: PNG (non-interlaced), baseline JPEG and binary PNM -> 8-bit RGB, row 0 = top.
  * rgb may be NULL to query the size. */
 int mohost_read_image(const char* path, int32_t* width, int32_t* height, uint8_t* rgb, uint64_t rgbCapacity);
 /* clear_scene + set_params + add_texture + add_* + set_lights + build_accel on ctx */

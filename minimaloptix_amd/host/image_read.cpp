@@ -1,7 +1,7 @@
 // image_read.cpp -- decoder behind readImage(): what QImage(path) + pixelColor() give the reference's
 // texture upload (MinimalOptiX.cpp:446-466).  The image has no zlib/libpng headers, so inflate
 // (RFC 1951) and the PNG container (filters, bit depths, palette; non-interlaced) are implemented
-// here; binary PNM (P5/P6) is read as well.  JPEG is not supported.
+// here; binary PNM (P5/P6) is read as well, baseline JPEG in jpeg_read.cpp.
 #include "image_io.h"
 
 #include <cstdio>
@@ -232,6 +232,8 @@ bool decodePNM(const std::vector<uint8_t>& file, int& width, int& height, std::v
 
 }  // namespace
 
+bool decodeJPEG(const std::vector<uint8_t>& file, int& width, int& height, std::vector<uint8_t>& rgb, std::string& err);   // jpeg_read.cpp
+
 bool readImage(const std::string& path, int& width, int& height, std::vector<uint8_t>& rgbTopDown, std::string& err) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) { err = "cannot open image " + path; return false; }
@@ -243,7 +245,8 @@ bool readImage(const std::string& path, int& width, int& height, std::vector<uin
   bool ok;
   if (file.size() > 8 && !memcmp(file.data(), sig, 8)) ok = decodePNG(file, width, height, rgbTopDown, err);
   else if (file.size() > 2 && file[0] == 'P' && (file[1] == '5' || file[1] == '6')) ok = decodePNM(file, width, height, rgbTopDown, err);
-  else { err = "unsupported image format (PNG and binary PNM are read)"; ok = false; }
+  else if (file.size() > 3 && file[0] == 0xff && file[1] == 0xd8 && file[2] == 0xff) ok = decodeJPEG(file, width, height, rgbTopDown, err);
+  else { err = "unsupported image format (PNG, baseline JPEG and binary PNM are read)"; ok = false; }
   if (!ok) err = path + ": " + err;
   return ok;
 }

@@ -30,8 +30,11 @@ def test_png_and_pnm_decoder(tmp_path):
     assert np.array_equal(_read_image(tmp_path / "r.ppm"), ramp)
     (tmp_path / "g.pgm").write_bytes(b"P5\n4 2\n255\n" + bytes(range(8)))
     assert np.array_equal(_read_image(tmp_path / "g.pgm")[..., 1].reshape(-1), np.arange(8))
-    (tmp_path / "bad.jpg").write_bytes(b"\xff\xd8\xff\xe0 not really")
+    (tmp_path / "bad.gif").write_bytes(b"GIF89a not really")
     with pytest.raises(RuntimeError, match="unsupported image format"):
+        _read_image(tmp_path / "bad.gif")
+    (tmp_path / "bad.jpg").write_bytes(b"\xff\xd8\xff\xe0 not really")
+    with pytest.raises(RuntimeError):
         _read_image(tmp_path / "bad.jpg")
     with pytest.raises(RuntimeError, match="cannot open"):
         _read_image(tmp_path / "missing.png")
@@ -137,3 +140,29 @@ def test_textured_scene_hostsim_matches_oracle(tmp_path):
         m["albedoID"] = 0
     plain, _ = O.Scene(d).render(seeds)
     assert rmse(plain, ref) / len(seeds) > 1e-2
+
+
+def test_jpeg_decoder_against_libjpeg(tmp_path):
+    """Baseline JPEG (what QImage reads through libjpeg): islow IDCT, fancy upsampling and the YCbCr tables are
+    restated so that the pixels equal libjpeg-turbo's (via PIL) for 4:4:4 / 4:2:2 / 4:2:0, grayscale, optimised
+    Huffman tables, restart intervals and odd sizes."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(1)
+    yy, xx = np.mgrid[0:61, 0:83]
+    smooth = np.stack([(xx * 3 + yy) % 256, (yy * 4) % 256, (xx * 2 + yy * 2) % 256], -1).astype(np.uint8)
+    noise = (rng.rand(61, 83, 3) * 255).astype(np.uint8)
+    p = tmp_path / "t.jpg"
+    for name, arr in (("smooth", smooth), ("noise", noise), ("tiny", smooth[:1, :1]), ("thin", smooth[:17, :3]), ("m16", smooth[:32, :48])):
+        for sub in (0, 1, 2):
+            for q, extra in ((30, {}), (75, {"optimize": True}), (95, {"restart_marker_blocks": 3})):
+                Image.fromarray(arr, "RGB").save(p, quality=q, subsampling=sub, **extra)
+                assert np.array_equal(_read_image(p), np.asarray(Image.open(p).convert("RGB"))), (name, sub, q, extra)
+        Image.fromarray(arr, "RGB").convert("L").save(p, quality=80)
+        assert np.array_equal(_read_image(p), np.asarray(Image.open(p).convert("RGB"))), (name, "gray")
+    Image.fromarray(smooth, "RGB").save(p, progressive=True)
+    with pytest.raises(RuntimeError, match="progressive"):
+        _read_image(p)
+    raw = p.read_bytes()
+    (tmp_path / "cut.jpg").write_bytes(raw[:40])
+    with pytest.raises(RuntimeError):
+        _read_image(tmp_path / "cut.jpg")
