@@ -201,32 +201,38 @@ PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, St
 
 // One leaf (count x 48-byte triangle records) for a lane with tv.node < 0.  The records of up to four
 // triangles are fetched together (one memory round trip per chunk instead of one per triangle; slots past the
-// end of the leaf re-read its last record, which costs no extra line) and then tested in order.
+// end of the leaf re-read its last record, which costs no extra line) and then tested in order.  A caller that
+// knows the leaf early (queuekernel.hip: from LDS) issues leaf_fetch4 for the first chunk itself, together with
+// its other loads.
+struct LeafChunk { v3 p0[4], e0[4], e1[4]; int mat[4], prim[4]; };
+PT_HD void leaf_fetch4(const SceneView& sc, int leafRef, int base, LeafChunk& ch) {
+  const int first = leaf_first(leafRef), count = leaf_count(leafRef);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int k = base + j < count ? base + j : count - 1;
+    const Tri48* tp = sc.tris + (first + k);
+    ch.p0[j] = tp->p0; ch.e0[j] = tp->e0; ch.e1[j] = tp->e1; ch.mat[j] = tp->mat; ch.prim[j] = tp->prim;
+  }
+}
 template <bool CNT, class Stack>
-PT_HD void trav_leaf_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
+PT_HD void trav_leaf_step_fetched(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct, LeafChunk& ch) {
   {
     const int first = leaf_first(tv.node), count = leaf_count(tv.node);
     const int triBase = sc.nSpheres + sc.nQuads;
     bool terminated = false;
     for (int base = 0; base < count && !terminated; base += 4) {
-      v3 p0[4], e0[4], e1[4]; int mat[4], prim[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int k = base + j < count ? base + j : count - 1;
-        const Tri48* tp = sc.tris + (first + k);
-        p0[j] = tp->p0; e0[j] = tp->e0; e1[j] = tp->e1; mat[j] = tp->mat; prim[j] = tp->prim;
-      }
+      if (base > 0) leaf_fetch4(sc, tv.node, base, ch);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (base + j < count && !terminated) {
           cnt<CNT>(ct.triTests);
           v3 n; float t, be, ga;
-          if (tri_test(ps.o, ps.d, ps.tmin, ps.tmax, p0[j], e0[j], e1[j], n, t, be, ga)) {   // meshIntersect, Geometry.cu:121-160
+          if (tri_test(ps.o, ps.d, ps.tmin, ps.tmax, ch.p0[j], ch.e0[j], ch.e1[j], n, t, be, ga)) {   // meshIntersect, Geometry.cu:121-160
             if (ps.kind == RK_RADIANCE) {
-              if (potential(t, triBase + prim[j], ps.tmin, tv.tbest, tv.bestPrim)) {
-                tv.tbest = t; tv.bestPrim = triBase + prim[j]; tv.bestTri = first + base + j; tv.beta = be; tv.gamma = ga;
+              if (potential(t, triBase + ch.prim[j], ps.tmin, tv.tbest, tv.bestPrim)) {
+                tv.tbest = t; tv.bestPrim = triBase + ch.prim[j]; tv.bestTri = first + base + j; tv.beta = be; tv.gamma = ga;
               }
-            } else if (shadow_any_hit(sc, mat[j], tv.att)) terminated = true;
+            } else if (shadow_any_hit(sc, ch.mat[j], tv.att)) terminated = true;
           }
         }
       }
@@ -234,6 +240,12 @@ PT_HD void trav_leaf_step(const SceneView& sc, const PathState& ps, Trav& tv, St
     if (terminated) tv.node = kTravDone;
     else trav_pop(tv, st);
   }
+}
+template <bool CNT, class Stack>
+PT_HD void trav_leaf_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
+  LeafChunk ch;
+  leaf_fetch4(sc, tv.node, 0, ch);
+  trav_leaf_step_fetched<CNT>(sc, ps, tv, st, ct, ch);
 }
 
 // One traversal step for a lane with tv.node != kTravDone (if-if form; the kernels use the

@@ -272,6 +272,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       PathState ps; Trav tv;
       ps.tmin = sc.epsT; ps.mode = M_TRACE;
       const v4 na = W.nodeA[slot], nb = W.nodeB[slot];
+      // the leaf is known from LDS: its triangles are requested together with the slot's warm rows (one round trip)
+      LeafChunk ch;
+      leaf_fetch4(sc, f2i(nb.w), 0, ch);
       const SlotCold* cs = cold + slot;
       const v4 w0 = slot_load(reinterpret_cast<const v4*>(&cs->dx));
       const i4 w1 = slot_load(reinterpret_cast<const i4*>(&cs->kind));
@@ -281,7 +284,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       tv.node = f2i(nb.w); tv.sp = W.stack[slot][0] & ~kShadeFlag; tv.bestTri = w1.y; tv.bestPrim = w1.z;
       tv.beta = w2.x; tv.gamma = w2.y; tv.att = mk3(w2.x, w2.y, w2.z);
       SlotStack st = make_stack(slot);
-      trav_leaf_step<CNT>(sc, ps, tv, st, ct);
+      trav_leaf_step_fetched<CNT>(sc, ps, tv, st, ct, ch);
       W.nodeA[slot].w = tv.tbest;
       W.nodeB[slot].w = i2f(tv.node);
       W.stack[slot][0] = tv.sp | ((ps.kind == RK_SHADOW || tv.bestPrim >= 0) ? kShadeFlag : 0);
