@@ -335,3 +335,13 @@ def test_work_item_order_does_not_change_the_image(gpu_ctx):
     assert all(np.array_equal(images[0], im) for im in images[1:])
     o, _ = oracle_scene(hs).render(seeds)
     assert rmse(images[0] / 6, o / 6) <= RMSE_TIGHT
+
+
+def test_randomised_option_combinations_match_variant0():
+    """tools/gpu_fuzz.py: random frame sizes, sample counts, partitions and scheduler options (kernel variant, leaf
+    size, work order, thresholds, workgroups per CU, multi-pass sample buffer) against the per-lane kernel."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CASES="10", SEED="7")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
