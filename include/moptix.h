@@ -179,10 +179,17 @@ int moptix_render_counted(moptix_context ctx, const int32_t* seeds, int32_t nSee
  * tiles t (raster order) with t % nRanks == rank.  Default (0,1) = whole frame. */
 int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
 
-/* tuning knobs: "kernel_variant" (0 = one path per lane, 1 = path pool with wave-level
- * compaction), "leaf_size" (1..8, before build_accel), "blocks_per_cu", "exit_threshold"
- * (variant 0), "pool_slots" (128|192|256), "refill_lanes", "starve_lanes" (variant 1),
- * "sample_buffer_mb" (budget of the per-sample buffer; larger batches run in passes).
+/* tuning knobs (none of them changes a bit of the image):
+ *   "kernel_variant"   0 = one path per lane, 1 = per-wave path pool, 2 = per-wave stage queues,
+ *                      3 = workgroup-shared stage queues (default; scenes without triangles always use 0)
+ *   "leaf_size"        1..8 triangles per BVH leaf (default 4; takes effect at the next build_accel)
+ *   "tile_major"       hand-out order of the (pixel, sample) work items: 0 = sample-major, 1 = all samples of an
+ *                      8x8 tile back to back, tiles with the deepest paths of earlier launches first (default),
+ *                      2 = as 1 with one pixel's samples per wave
+ *   "blocks_per_cu"    resident workgroups per CU (default 3)
+ *   "swap_lanes", "starve_lanes"   node-loop swap / starvation thresholds of variants 2 and 3
+ *   "exit_threshold" (variant 0), "pool_slots" (128|192|256), "refill_lanes", "leaf_threshold" (variant 1)
+ *   "sample_buffer_mb" budget of the per-sample buffer; larger batches run in passes
  * Unknown names -> MOPTIX_ERR_INVALID. */
 int moptix_set_option(moptix_context ctx, const char* name, int32_t value);
 int moptix_get_option(moptix_context ctx, const char* name, int32_t* value);
