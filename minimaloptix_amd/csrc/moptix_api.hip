@@ -75,7 +75,7 @@ struct moptix_context_t {
   int optTileMajor = 1;
   long long tileHistoryTiles = -1;
   DevBuf<unsigned int> dTileCost, dTileCostSorted; DevBuf<int> dTileOrder, dTileIota; DevBuf<uint8_t> dSortTmp;
-  int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 8192, optLeafThreshold = 16, optSwapLanes = 24;
+  int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 8192, optLeafThreshold = 16, optSwapLanes = 32;
   unsigned long long lastExtra[5] = { 0, 0, 0, 0, 0 };
 
   double kernelMs = 0.0, reduceMs = 0.0; uint64_t nLaunches = 0;
