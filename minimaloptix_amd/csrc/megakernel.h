@@ -26,9 +26,10 @@ struct LaunchArgs {
   int swapLanes;                    // leave the node loop once this many lanes stand at a leaf / have finished
   int ovfDepth;                     // ints of stack overflow per slot
   // hand-out order of the work items (queuekernel.hip): tile-major, tiles with the deepest paths first
-  int tileMajor;                    // 0 = sample-major in raster tile order (item k handed out as k)
-  const int* tileOrder;             // local tile visited i-th (device, nItems/64 entries) or nullptr = raster order
-  unsigned int* tileCost;           // per local tile: deepest path seen so far (device) or nullptr
+  int tileMajor;                    // 0 = sample-major in raster tile order (item k handed out as k); 1, 2 = by tile; 3 = by pixel
+  int unitShift;                    // log2 of the slots per history unit: 6 = 8x8 tile, 0 = pixel
+  const int* tileOrder;             // unit visited i-th (device, nItems >> unitShift entries) or nullptr = raster order
+  unsigned int* tileCost;           // per unit: deepest path seen so far (device) or nullptr
 };
 constexpr int kDeepPath = 8;        // paths at least this deep are recorded in tileCost
 
@@ -51,6 +52,10 @@ __device__ __forceinline__ bool item_to_pixel(const LaunchArgs& a, int k, int& s
 // (a chain of ~1000 dependent rays, ~28 ms) then start early and overlap the bulk instead of forming the tail.
 __device__ __forceinline__ int handout_to_item(const LaunchArgs& a, int k) {
   if (!a.tileMajor) return k;
+  if (a.tileMajor == 3) {                               // all samples of a pixel back to back, deepest pixels first
+    const int ui = k / a.nSeeds, sample = k - ui * a.nSeeds;
+    return sample * a.nItems + (a.tileOrder ? a.tileOrder[ui] : ui);
+  }
   const int per = a.nSeeds << 6;                       // items of one tile
   const int ti = k / per, r = k - ti * per;
   const int lt = a.tileOrder ? a.tileOrder[ti] : ti;

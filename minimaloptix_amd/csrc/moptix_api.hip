@@ -148,6 +148,8 @@ int read_stats(moptix_context c, moptix_stats* stats) {
     if (h[32]) fprintf(stderr, "[moptix] swap detail: local %.1f%% lock-wait %.1f%% txn %.1f%% idle %.1f%% | batch detail: load %.1f%% run %.1f%% store %.1f%% | "
                        "iterations %llu transactions %llu (cycles/iter %.0f)\n", 100 * h[24] / tt, 100 * h[25] / tt, 100 * h[26] / tt, 100 * h[27] / tt,
                        100 * h[28] / tt, 100 * h[29] / tt, 100 * h[30] / tt, h[32], h[31], tt / (double)h[32]);
+    if (h[38]) fprintf(stderr, "[moptix] timeline (100 MHz clock): items ran out %.2f ms after the first wave started, last wave left %.2f ms after that\n",
+                       (double)(h[37] - h[36]) * 1e-5, (double)(h[38] - h[37]) * 1e-5);
     if (h[32]) fprintf(stderr, "[moptix] batch iterations executing on_result %llu, on_lights %llu, new item %llu (batches %llu)\n", h[33], h[34], h[35], h[11]);
     if (h[22]) fprintf(stderr, "[moptix] node steps %llu (%.1f lanes avg), leaf passes %llu (%.1f lanes avg)\n", h[9] - h[22],
             (double)(h[10] - h[23]) / (double)(h[9] - h[22]), h[22], (double)h[23] / (double)h[22]);
@@ -213,21 +215,23 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   HIPCHK(c, c->dWork.ensure(2), "alloc work counter");   // [0] work counter, [1] watchdog flag
   a.tileMajor = useQueue ? c->optTileMajor : 0;
   a.tileOrder = nullptr; a.tileCost = nullptr;
+  a.unitShift = a.tileMajor == 3 ? 0 : 6;
+  const long long historyUnits = (localTiles * 64) >> a.unitShift;
   if (a.tileMajor) {
-    if (c->tileHistoryTiles != localTiles) {             // new frame size / partition: forget the history
-      HIPCHK(c, c->dTileCost.ensure((size_t)localTiles), "alloc tile cost");
-      HIPCHK(c, c->dTileCostSorted.ensure((size_t)localTiles), "alloc tile cost");
-      HIPCHK(c, c->dTileOrder.ensure((size_t)localTiles), "alloc tile order");
-      std::vector<int> iota((size_t)localTiles);
+    if (c->tileHistoryTiles != historyUnits) {           // new frame size / partition / granularity: forget the history
+      HIPCHK(c, c->dTileCost.ensure((size_t)historyUnits), "alloc tile cost");
+      HIPCHK(c, c->dTileCostSorted.ensure((size_t)historyUnits), "alloc tile cost");
+      HIPCHK(c, c->dTileOrder.ensure((size_t)historyUnits), "alloc tile order");
+      std::vector<int> iota((size_t)historyUnits);
       for (size_t i = 0; i < iota.size(); i++) iota[i] = (int)i;
       HIPCHK(c, c->dTileIota.upload(iota, c->stream), "upload tile ids");
-      HIPCHK(c, hipMemsetAsync(c->dTileCost.p, 0, sizeof(unsigned int) * (size_t)localTiles, c->stream), "zero tile cost");
+      HIPCHK(c, hipMemsetAsync(c->dTileCost.p, 0, sizeof(unsigned int) * (size_t)historyUnits, c->stream), "zero tile cost");
       size_t tmpBytes = 0;
       HIPCHK(c, rocprim::radix_sort_pairs_desc(nullptr, tmpBytes, c->dTileCost.p, c->dTileCostSorted.p, c->dTileIota.p, c->dTileOrder.p,
-                                               (size_t)localTiles, 0, 32, c->stream), "size tile sort");
+                                               (size_t)historyUnits, 0, 32, c->stream), "size tile sort");
       HIPCHK(c, c->dSortTmp.ensure(tmpBytes), "alloc sort scratch");
       HIPCHK(c, hipStreamSynchronize(c->stream), "sync tile history");    // iota staging dies here
-      c->tileHistoryTiles = localTiles;
+      c->tileHistoryTiles = historyUnits;
     }
     a.tileOrder = c->dTileOrder.p; a.tileCost = c->dTileCost.p;
   }
@@ -235,6 +239,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   if (counted) {
     HIPCHK(c, c->dCounters.ensure(40), "alloc counters");
     HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * 40, c->stream), "zero counters");
+    HIPCHK(c, hipMemsetAsync(c->dCounters.p + 36, 0xff, sizeof(unsigned long long) * 2, c->stream), "init min counters");
     a.counters = c->dCounters.p;
   }
   std::vector<int> hs(seeds, seeds + nSeeds);
@@ -248,7 +253,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
       // tiles in descending order of the deepest path seen so far (stable: ties stay in raster order)
       size_t tmpBytes = c->dSortTmp.n;
       HIPCHK(c, rocprim::radix_sort_pairs_desc(c->dSortTmp.p, tmpBytes, c->dTileCost.p, c->dTileCostSorted.p, c->dTileIota.p, c->dTileOrder.p,
-                                               (size_t)localTiles, 0, 32, c->stream), "sort tiles");
+                                               (size_t)historyUnits, 0, 32, c->stream), "sort tiles");
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
     if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, c->optVariant == 3, counted), "launch queue megakernel");
@@ -260,6 +265,18 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     c->asyncPending = true;
     const bool last = first + perPass >= nSeeds;
     if (!last || blocking) { if ((rc = moptix_sync(c)) != MOPTIX_OK) return rc; }
+  }
+  if (blocking && a.tileCost && getenv("MOPTIX_DEBUG")) {       // how the deepest-path history is distributed over the tiles
+    std::vector<unsigned int> cost((size_t)historyUnits);
+    HIPCHK(c, hipMemcpy(cost.data(), c->dTileCost.p, sizeof(unsigned int) * cost.size(), hipMemcpyDeviceToHost), "read tile cost");
+    size_t hist[6] = { 0, 0, 0, 0, 0, 0 };                        // 0, 8..15, 16..63, 64..255, 256+, first half of the tiles holding 256+
+    for (size_t i = 0; i < cost.size(); i++) {
+      const unsigned int v = cost[i];
+      hist[v == 0 ? 0 : v < 16 ? 1 : v < 64 ? 2 : v < 256 ? 3 : 4]++;
+      if (v >= 256 && i < cost.size() / 2) hist[5]++;
+    }
+    fprintf(stderr, "[moptix] depth history (%zu units): none %zu, depth 8-15 %zu, 16-63 %zu, 64-255 %zu, capped %zu (of which %zu in the first half)\n",
+            cost.size(), hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
   }
   if (blocking && counted && stats) return read_stats(c, stats);
   return MOPTIX_OK;
@@ -548,7 +565,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "swap_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "swap_lanes in [1,64]"); c->optSwapLanes = value; }
   else if (!strcmp(name, "refill_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "refill_lanes in [1,64]"); c->optRefillLanes = value; }
   else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
-  else if (!strcmp(name, "tile_major")) { if (value < 0 || value > 2) return fail(c, MOPTIX_ERR_INVALID, "tile_major in {0,1,2}"); c->optTileMajor = value; }
+  else if (!strcmp(name, "tile_major")) { if (value < 0 || value > 3) return fail(c, MOPTIX_ERR_INVALID, "tile_major in {0,1,2,3}"); c->optTileMajor = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
 }

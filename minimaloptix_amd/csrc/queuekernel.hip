@@ -244,6 +244,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
   uint32_t nodeSteps = 0, nodeLanes = 0, leafPasses = 0, leafLanes = 0, batches = 0, batchLanes = 0, idleSpins = 0;
   unsigned long long tBatch = 0, tSwap = 0, tNode = 0, tLeaf = 0, tStamp = 0;
   const unsigned long long tStart = CNT ? __builtin_amdgcn_s_memtime() : 0ull;
+  [[maybe_unused]] const unsigned long long rtStart = CNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #define PT_STAMP(acc) do { if (CNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tStamp; tStamp = now_; } } while (0)
   tStamp = tStart;
 
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     for (;;) {
       if (have && ps.mode == M_NEW_SAMPLE) {
         store_sample(a, ps.item, ps.accum);
-        if (a.tileCost != nullptr && ps.depth >= kDeepPath) atomicMax(a.tileCost + ((ps.item % a.nItems) >> 6), (unsigned int)ps.depth);
+        if (a.tileCost != nullptr && ps.depth >= kDeepPath) atomicMax(a.tileCost + ((ps.item % a.nItems) >> a.unitShift), (unsigned int)ps.depth);
         ps.mode = M_NEW_PIXEL;
       }
       // lanes that arrive with a finished ray go first; the lanes that only need a new work item wait for them, so
@@ -357,6 +358,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         } else {  // M_NEW_PIXEL: next (pixel, sample) work item
           int k = atomicAdd(a.workCounter, 1);
           k = (k >= a.nWork) ? -1 : handout_to_item(a, k);
+          if (CNT && k < 0) atomicMin(a.counters + 37, (unsigned long long)__builtin_amdgcn_s_memrealtime());   // first time the items ran out
           int s;
           if (k < 0) { ps.mode = M_DONE; }
           else if (item_to_pixel(a, k, s, ps.pixel)) { ps.item = k; begin_sample<CNT>(sc, ps, a.seeds[s], ct); }
@@ -540,6 +542,8 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       atomicAdd(&c[16], tBatch); atomicAdd(&c[17], tSwap); atomicAdd(&c[18], tNode); atomicAdd(&c[19], tLeaf);
       atomicAdd(&c[21], __builtin_amdgcn_s_memtime() - tStart);
       atomicAdd(&c[22], (unsigned long long)leafPasses); atomicAdd(&c[23], (unsigned long long)leafLanes);
+      atomicMax(&c[38], (unsigned long long)__builtin_amdgcn_s_memrealtime());   // last wave out
+      atomicMin(&c[36], rtStart);
       atomicAdd(&c[24], tLocal); atomicAdd(&c[25], tLock); atomicAdd(&c[26], tTxn); atomicAdd(&c[27], tIdle);
       atomicAdd(&c[33], nIterResult); atomicAdd(&c[34], nIterLights); atomicAdd(&c[35], nIterGen);
       atomicAdd(&c[28], tBLoad); atomicAdd(&c[29], tBRun); atomicAdd(&c[30], tBStore); atomicAdd(&c[31], nTxn); atomicAdd(&c[32], nIter);

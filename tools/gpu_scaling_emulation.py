@@ -1,0 +1,23 @@
+"""Strong-scaling estimate on ONE GPU: renders each rank's tile partition of the coffee frame in turn and
+reports max-over-ranks time against the 1-GPU frame (load balance + per-launch constants; no communication)."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from common import M   # noqa: E402
+ctx = M.Context(0)
+W, H = 1920, 1080
+spp = int(os.environ.get("SPP", "256"))
+hs = M.HostScene("file:coffee", W, H)
+seeds = M.launch_seeds(spp)
+def timed():
+    best = 1e9
+    for rep in range(3):
+        ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); ms, n = ctx.kernel_time(); best = min(best, ms + ctx.reduce_time())
+    return best
+ctx.load(hs); t1 = timed()
+print("N=1: %.1f ms" % t1, flush=True)
+for n in (2, 4, 8):
+    ts = []
+    for r in range(n):
+        ctx.set_partition(r, n); ctx.load(hs); ts.append(timed())
+    print("N=%d: max %.1f ms min %.1f ms -> efficiency %.1f %% (compute only)" % (n, max(ts), min(ts), 100 * t1 / (n * max(ts))), flush=True)
