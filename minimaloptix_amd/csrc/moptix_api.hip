@@ -150,6 +150,8 @@ int read_stats(moptix_context c, moptix_stats* stats) {
                        100 * h[28] / tt, 100 * h[29] / tt, 100 * h[30] / tt, h[32], h[31], tt / (double)h[32]);
     if (h[38]) fprintf(stderr, "[moptix] timeline (100 MHz clock): items ran out %.2f ms after the first wave started, last wave left %.2f ms after that\n",
                        (double)(h[37] - h[36]) * 1e-5, (double)(h[38] - h[37]) * 1e-5);
+    if (h[39]) fprintf(stderr, "[moptix] node runs %llu: node-ready slots waiting in the wave's ring %.1f, leaf ring %.1f (averages at the start of a run)\n",
+                       h[39], (double)h[15] / (double)h[39], (double)h[13] / (double)h[39]);
     if (h[32]) fprintf(stderr, "[moptix] batch iterations executing on_result %llu, on_lights %llu, new item %llu (batches %llu)\n", h[33], h[34], h[35], h[11]);
     if (h[22]) fprintf(stderr, "[moptix] node steps %llu (%.1f lanes avg), leaf passes %llu (%.1f lanes avg)\n", h[9] - h[22],
             (double)(h[10] - h[23]) / (double)(h[9] - h[22]), h[22], (double)h[23] / (double)h[22]);

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
 
   // sub-phase clocks of the counting build
   unsigned long long tLocal = 0, tLock = 0, tTxn = 0, tIdle = 0, tBLoad = 0, tBRun = 0, tBStore = 0, nTxn = 0, nIter = 0;
-  unsigned long long tSub = 0, nIterResult = 0, nIterLights = 0, nIterGen = 0;
+  unsigned long long tSub = 0, nIterResult = 0, nIterLights = 0, nIterGen = 0, nodeRuns = 0, ringBacklog = 0, leafBacklog = 0;
 #define PT_SUB0() do { if (CNT) tSub = __builtin_amdgcn_s_memtime(); } while (0)
 #define PT_SUB(acc) do { if (CNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tSub; tSub = now_; } } while (0)
   // queue bookkeeping: registers (wave-uniform); with SHARED they mirror LDS inside a transaction
@@ -513,6 +513,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     if (pass > 0) { run_batch(mySlot, pass == 1); PT_STAMP(tBatch); continue; }
 
     // ---- node loop: until swapLanes lanes have left the node set ----
+    if (CNT) { nodeRuns++; ringBacklog += (unsigned long long)nqCount; leafBacklog += (unsigned long long)lqCount; }
     {
       SlotStack st = make_stack(ns >= 0 ? ns : 0);
       for (;;) {
@@ -545,6 +546,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       atomicMax(&c[38], (unsigned long long)__builtin_amdgcn_s_memrealtime());   // last wave out
       atomicMin(&c[36], rtStart);
       atomicAdd(&c[24], tLocal); atomicAdd(&c[25], tLock); atomicAdd(&c[26], tTxn); atomicAdd(&c[27], tIdle);
+      atomicAdd(&c[39], nodeRuns); atomicAdd(&c[15], ringBacklog); atomicAdd(&c[13], leafBacklog);
       atomicAdd(&c[33], nIterResult); atomicAdd(&c[34], nIterLights); atomicAdd(&c[35], nIterGen);
       atomicAdd(&c[28], tBLoad); atomicAdd(&c[29], tBRun); atomicAdd(&c[30], tBStore); atomicAdd(&c[31], nTxn); atomicAdd(&c[32], nIter);
     }
