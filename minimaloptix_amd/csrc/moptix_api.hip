@@ -679,20 +679,23 @@ int moptix_debug_trace(moptix_context c, const float* rays, int32_t n, float* ou
   if (n == 0) return MOPTIX_OK;
   HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
   float *dR = nullptr, *dT = nullptr; int* dP = nullptr; int* dOvf = nullptr;
-  HIPCHK(c, hipMalloc((void**)&dR, sizeof(float) * 8 * (size_t)n), "alloc rays");
-  HIPCHK(c, hipMalloc((void**)&dT, sizeof(float) * (size_t)n), "alloc t");
-  HIPCHK(c, hipMalloc((void**)&dP, sizeof(int) * (size_t)n), "alloc prim");
-  if (c->bvh.stackBound > megakernel_lds_stack_entries()) {
+  hipError_t e = hipMalloc((void**)&dR, sizeof(float) * 8 * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc((void**)&dT, sizeof(float) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc((void**)&dP, sizeof(int) * (size_t)n);
+  if (e == hipSuccess && c->bvh.stackBound > megakernel_lds_stack_entries()) {
     const size_t threads = ((size_t)n + 255) / 256 * 256;
-    HIPCHK(c, hipMalloc((void**)&dOvf, sizeof(int) * threads * (size_t)(c->bvh.stackBound - megakernel_lds_stack_entries() + 1)), "alloc overflow");
+    e = hipMalloc((void**)&dOvf, sizeof(int) * threads * (size_t)(c->bvh.stackBound - megakernel_lds_stack_entries() + 1));
   }
   SceneView v; fill_view(c, v);
-  hipError_t e = hipMemcpyAsync(dR, rays, sizeof(float) * 8 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dR, rays, sizeof(float) * 8 * (size_t)n, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = launch_debug_trace(c->stream, v, dR, n, dT, dP, dOvf);
   if (e == hipSuccess) e = hipMemcpyAsync(outT, dT, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(outPrim, dP, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(dR); (void)hipFree(dT); (void)hipFree(dP); if (dOvf) (void)hipFree(dOvf);
+  if (dR) (void)hipFree(dR);
+  if (dT) (void)hipFree(dT);
+  if (dP) (void)hipFree(dP);
+  if (dOvf) (void)hipFree(dOvf);
   if (e != hipSuccess) return hipFail(c, e, "debug trace");
   return MOPTIX_OK;
 }
