@@ -98,7 +98,7 @@ typedef struct moptix_params {
 typedef struct moptix_stats {
   uint64_t samples;              /* camera samples traced                                 */
   uint64_t primaryRays, bounceRays, shadowRays;
-  uint64_t nodeFetches;          /* 64-byte two-child BVH nodes fetched                   */
+  uint64_t nodeFetches;          /* 128-byte four-child BVH nodes fetched (one L2 line)   */
   uint64_t triTests;             /* 48-byte triangle records tested                       */
   uint64_t closestHits;          /* closest-hit shading fetches                           */
   uint64_t lightLoads;           /* LightParams records read for NEE                      */
@@ -212,7 +212,7 @@ int moptix_kernel_time(moptix_context ctx, double* totalMs, uint64_t* nLaunches,
 /* device time of the ordered sample reductions that followed those launches */
 int moptix_reduce_time(moptix_context ctx, double* totalMs);
 
-/* debug/validation: copy the built BVH to host (nodes: nNodes*64 B, tris: nTriangles*48 B,
+/* debug/validation: copy the built BVH to host (nodes: nNodes*128 B four-child nodes, tris: nTriangles*48 B,
  * triPrimIds: nTriangles int32 = original face index of each record). Any pointer may be NULL. */
 int moptix_debug_read_accel(moptix_context ctx, void* nodes, void* tris, int32_t* triPrimIds);
 /* nearest-hit query for n rays (BVH-vs-brute-force tests): rays = n x {ox,oy,oz,dx,dy,dz,tmin,tmax};

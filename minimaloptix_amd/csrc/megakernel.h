@@ -10,7 +10,7 @@ struct LaunchArgs {
   const int* seeds; int nSeeds;     // launch seeds, one sample per pixel each (device memory)
   float* accum;                     // accuBuffer: float3 W*H, row 0 = bottom
   float* sampleBuf;                 // per-sample results: float3 [nSeeds][nItems]
-  int* workCounter;                 // global work-item counter (zeroed before the launch)
+  int* workCounter;                 // [0] global work-item counter, [1] watchdog flag (both zeroed before the launch)
   int nItems;                       // pixels-slots of this rank = local tiles * 64
   int nWork;                        // work items = nSeeds * nItems, item k = (sample k / nItems, slot k % nItems)
   int tilesX; int rank, nRanks;     // 8x8 tile grid + tile-interleaved partition
@@ -25,6 +25,7 @@ struct LaunchArgs {
   // variant 2 (queuekernel.hip)
   int swapLanes;                    // leave the node loop once this many lanes stand at a leaf / have finished
   int ovfDepth;                     // ints of stack overflow per slot
+  unsigned long long watchdogTicks; // a wave gives up after this many 100 MHz ticks (sets workCounter[1]; the pass is then not reduced)
   // hand-out order of the work items (queuekernel.hip): tile-major, tiles with the deepest paths first
   int tileMajor;                    // 0 = sample-major in raster tile order (item k handed out as k); 1, 2 = by tile; 3 = by pixel
   int unitShift;                    // log2 of the slots per history unit: 6 = 8x8 tile, 0 = pixel

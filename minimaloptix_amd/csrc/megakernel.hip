@@ -208,6 +208,7 @@ hipError_t launch_debug_trace(hipStream_t stream, const SceneView& sc, const flo
 __global__ void k_reduce_samples(LaunchArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.nItems) return;
+  if (a.workCounter[1] != 0) return;      // the trace kernel gave up (watchdog): its sample buffer is incomplete
   int s, pixel;
   if (!item_to_pixel(a, i, s, pixel)) return;
   float* px = a.accum + 3 * (size_t)pixel;

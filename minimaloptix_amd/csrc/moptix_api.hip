@@ -78,6 +78,8 @@ struct moptix_context_t {
   int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 8192, optLeafThreshold = 16, optSwapLanes = 32;
   unsigned long long lastExtra[5] = { 0, 0, 0, 0, 0 };
 
+  std::vector<int> seedStaging;
+  int optWatchdogMs = 600000;
   double kernelMs = 0.0, reduceMs = 0.0; uint64_t nLaunches = 0;
   bool asyncPending = false;
 };
@@ -184,14 +186,18 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   if (a.nItems == 0) return MOPTIX_OK;
   const long long budget = (long long)c->optSampleBufMB << 20;
   long long perPass = budget / ((long long)a.nItems * 12);
-  perPass = std::min(perPass, 0x7fffffffLL / a.nItems);
+  const int nBlocks = c->numCUs * c->optBlocksPerCU;
+  // the work counter is a 32-bit int that every path slot bumps once more after the items ran out
+  const long long counterSlack = (long long)nBlocks * 1024 + 65536;
+  if ((long long)a.nItems + counterSlack > 0x7fffffffLL) return fail(c, MOPTIX_ERR_LIMIT, "frame too large");
+  perPass = std::min(perPass, (0x7fffffffLL - counterSlack) / a.nItems);
   perPass = std::max(1LL, std::min(perPass, (long long)nSeeds));
 
-  const int nBlocks = c->numCUs * c->optBlocksPerCU;
   const bool hasTris = a.scene.rootRef != kEmptyRef;
   const bool usePool = c->optVariant == 1 && hasTris;
   const bool useQueue = (c->optVariant == 2 || c->optVariant == 3) && hasTris;
   a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;
+  a.watchdogTicks = (unsigned long long)c->optWatchdogMs * 100000ull;      // s_memrealtime counts at 100 MHz
   if (useQueue) {
     a.ovfDepth = std::max(0, c->bvh.stackBound - queuekernel_lds_stack_entries() + 1);
     if (a.ovfDepth > 0) {
@@ -244,8 +250,8 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     HIPCHK(c, hipMemsetAsync(c->dCounters.p + 36, 0xff, sizeof(unsigned long long) * 2, c->stream), "init min counters");
     a.counters = c->dCounters.p;
   }
-  std::vector<int> hs(seeds, seeds + nSeeds);
-  HIPCHK(c, c->dSeeds.upload(hs, c->stream), "upload seeds");
+  c->seedStaging.assign(seeds, seeds + nSeeds);   // lives in the context: the copy below may still be in flight when an async render returns
+  HIPCHK(c, c->dSeeds.upload(c->seedStaging, c->stream), "upload seeds");
 
   for (long long first = 0; first < nSeeds; first += perPass) {
     const int n = (int)std::min(perPass, (long long)nSeeds - first);
@@ -311,7 +317,10 @@ int moptix_create(moptix_context* out, int device) {
   c->device = device; c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipFail(nullptr, e, "hipStreamCreate"); }
   c->ownStream = true;
-  if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess || (e = hipEventCreate(&c->ev2)) != hipSuccess) { delete c; return hipFail(nullptr, e, "hipEventCreate"); }
+  if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess || (e = hipEventCreate(&c->ev2)) != hipSuccess) {
+    (void)moptix_destroy(c);                       // releases the stream and whichever events exist
+    return hipFail(nullptr, e, "hipEventCreate");
+  }
   *out = c;
   return MOPTIX_OK;
 }
@@ -543,7 +552,7 @@ int moptix_sync(moptix_context c) {
     c->asyncPending = false;
     int flags[2] = { 0, 0 };
     if (c->dWork.p) HIPCHK(c, hipMemcpy(flags, c->dWork.p, sizeof(flags), hipMemcpyDeviceToHost), "read watchdog flag");
-    if (flags[1] != 0) return fail(c, MOPTIX_ERR_HIP, "render kernel hit its iteration watchdog (scheduler made no progress)");
+    if (flags[1] != 0) return fail(c, MOPTIX_ERR_HIP, "render kernel hit its watchdog (option watchdog_ms); this pass was not added to accuBuffer");
   }
   return MOPTIX_OK;
 }
@@ -568,6 +577,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "refill_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "refill_lanes in [1,64]"); c->optRefillLanes = value; }
   else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
   else if (!strcmp(name, "tile_major")) { if (value < 0 || value > 3) return fail(c, MOPTIX_ERR_INVALID, "tile_major in {0,1,2,3}"); c->optTileMajor = value; }
+  else if (!strcmp(name, "watchdog_ms")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "watchdog_ms >= 1"); c->optWatchdogMs = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
 }
@@ -585,6 +595,7 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "refill_lanes")) *value = c->optRefillLanes;
   else if (!strcmp(name, "starve_lanes")) *value = c->optStarveLanes;
   else if (!strcmp(name, "tile_major")) *value = c->optTileMajor;
+  else if (!strcmp(name, "watchdog_ms")) *value = c->optWatchdogMs;
   else if (!strcmp(name, "num_cus")) *value = c->numCUs;
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;

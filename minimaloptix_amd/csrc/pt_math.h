@@ -6,7 +6,7 @@
 //   AC2 cross= ( fma(a.y,b.z,-(a.z*b.y)), ... )
 //   AC3 length = sqrtf(dot), normalize = v*(1/sqrtf(dot)), v/s = v*(1/s)
 //   AC4 every other operator is a single IEEE binary32 op (build with -ffp-contract=off)
-//   AC5 sin/cos evaluated in binary64 and rounded once
+//   AC5 sin/cos are one specified binary32 algorithm (sincos_ac below: Cody-Waite reduction + fixed polynomials)
 //   AC7 point on ray = fma(t, d, o)
 // These are the optixu_math_namespace.h semantics the reference's programs rely on
 // (SURVEY.md Appendix A1), with the fused forms nvcc's default -fmad=true produces.

@@ -431,8 +431,10 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
   };
 
   unsigned int guard = 0;
+  const unsigned long long wdStart = __builtin_amdgcn_s_memrealtime();
   for (;;) {
-    if (++guard > (1u << 27)) { if (lane == 0) atomicOr(a.workCounter + 1, 1); break; }   // bounded: never hang the GPU
+    // bounded in wall-clock time (never hang the GPU): checked every 4096 iterations
+    if ((++guard & 4095u) == 0u && __builtin_amdgcn_s_memrealtime() - wdStart > a.watchdogTicks) { if (lane == 0) atomicOr(a.workCounter + 1, 1); break; }
     PT_SUB0(); if (CNT) nIter++;
     // ---- local bookkeeping (no lock): results of the last pass, swap, refill ----
     if (__ballot(pendDest != DEST_NONE) != 0ull) { local_push(pendDest, pendSlot); pendDest = DEST_NONE; }

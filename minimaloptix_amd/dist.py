@@ -10,6 +10,10 @@ torch.distributed over RCCL ("nccl") or gloo.  Nothing here is on the per-ray pa
 """
 import numpy as np
 
+# Sample split reorders the float32 additions of a pixel's samples (per-rank partial sums, then the reduce);
+# per-sample values are clamped to [0, 1], so the normalised image moves by a few ulps of 1: |delta| <= this bound.
+SAMPLE_SPLIT_TOL = 2e-6
+
 
 def tile_pixel_indices(width, height, rank, nranks):
     """Global pixel ids (y*W+x, row 0 = bottom) owned by `rank`, in work-item order."""

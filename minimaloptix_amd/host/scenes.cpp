@@ -155,6 +155,10 @@ static void loadFileScene(SceneDesc& s, const std::string& baseSceneFolder, cons
       for (size_t f = 0; f < nf; f++) {
         for (int fv = 0; fv < 3; ++fv) {
           const mobj::index_t& idx = shapes[sh].mesh.indices[f * 3 + fv];
+          // the reference reads attrib.vertices[3 * index] unchecked (:430-433); an index past the file's last "v" is an error here
+          if (idx.vertex_index < 0 || (size_t)idx.vertex_index >= attrib.vertices.size() / 3)
+            throw std::logic_error("face references vertex " + std::to_string(idx.vertex_index + 1) + " of " +
+                                   std::to_string(attrib.vertices.size() / 3) + " in " + scene.meshNames[i]);
           m.vIdx[f * 3 + fv] = idx.vertex_index;
           m.tIdx[f * 3 + fv] = idx.texcoord_index;
           m.nIdx[f * 3 + fv] = idx.normal_index;

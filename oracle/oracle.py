@@ -130,6 +130,8 @@ def lib():
         L.orc_trace_one.argtypes = [C.POINTER(OrcScene), f3, f3, C.c_int32, f3]
         L.orc_closest_hit.restype = C.c_int
         L.orc_closest_hit.argtypes = [C.POINTER(OrcScene), f3, f3, C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.orc_closest_hit_batch.restype = C.c_int
+        L.orc_closest_hit_batch.argtypes = [C.POINTER(OrcScene), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.orc_move_sphere.restype = None
         L.orc_move_sphere.argtypes = [f3, C.c_float, f3, C.c_float]
         L.orc_tex2d.argtypes = [C.POINTER(OrcTexture), C.c_float, C.c_float, C.c_float * 4]
@@ -264,8 +266,23 @@ class Scene:
         prim = lib().orc_closest_hit(C.byref(self.c), f3(*org), f3(*dirn), tmin, tmax, C.byref(t))
         return prim, t.value
 
+    def closest_hits(self, rays):
+        """rays: (n, 8) = o, d, tmin, tmax (the layout of moptix_debug_trace) -> (prim[n] or -1, t[n])."""
+        rays = np.ascontiguousarray(np.asarray(rays, np.float32).reshape(-1, 8))
+        prim = np.zeros(len(rays), np.int32); t = np.zeros(len(rays), np.float32)
+        lib().orc_closest_hit_batch(C.byref(self.c), _ptr(rays, C.c_float), len(rays), _ptr(prim, C.c_int32), _ptr(t, C.c_float))
+        return prim, t
+
 
 def image_from_accum(accum, spp):
     """MinimalOptiX.cpp:43-66 updateContent: clamp(accu/spp,0,1), flip rows (row 0 = bottom)."""
     img = np.clip(accum / np.float32(spp), 0.0, 1.0)
     return img[::-1].copy()
+
+
+def rgb8_from_accum(accum, n_accumulation):
+    """MinimalOptiX.cpp:43-66 updateContent down to the bytes of the RGB888 canvas: QColor::setRedF stores
+    qRound(v * 65535) in 16 bits, QImage::Format_RGB888 keeps the high byte; rows flipped (row 0 = top)."""
+    v = np.clip(np.asarray(accum, np.float32) / np.float32(n_accumulation), np.float32(0.0), np.float32(1.0))
+    q = (v * np.float32(65535.0) + np.float32(0.5)).astype(np.uint32) >> 8
+    return q.astype(np.uint8)[::-1].copy()

@@ -407,7 +407,8 @@ static const float* g_centroids;   /* qsort context (build is single threaded) *
 static int g_axis;
 static int cmp_centroid(const void* a, const void* b) {
   float ca = g_centroids[3 * (*(const int32_t*)a) + g_axis], cb = g_centroids[3 * (*(const int32_t*)b) + g_axis];
-  if (ca < cb) return -1; if (ca > cb) return 1;
+  if (ca < cb) return -1;
+  if (ca > cb) return 1;
   int32_t ia = *(const int32_t*)a, ib = *(const int32_t*)b;
   return (ia > ib) - (ia < ib);
 }
@@ -618,6 +619,21 @@ int orc_closest_hit(const OrcScene* sc, const float org[3], const float dir[3], 
   if (!r) return -1;
   if (tHit) *tHit = h.t;
   return h.prim;
+}
+
+/* n nearest-hit queries against one tree: rays = n x {o.xyz, d.xyz, tmin, tmax} (the layout of moptix_debug_trace) */
+int orc_closest_hit_batch(const OrcScene* sc, const float* rays, int n, int32_t* outPrim, float* outT) {
+  TriBVH* bvh = (sc->nFaces > 0 && !sc->bruteForceTris) ? bvh_build(sc) : NULL;
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int i = 0; i < n; i++) {
+    Ctx cx; memset(&cx, 0, sizeof(cx)); cx.sc = sc; cx.bvh = bvh;
+    const float* r = rays + 8 * (size_t)i;
+    Hit h;
+    if (find_closest(&cx, ld3(r), ld3(r + 3), r[6], r[7], &h)) { outPrim[i] = h.prim; outT[i] = h.t; }
+    else { outPrim[i] = -1; outT[i] = 0.f; }
+  }
+  bvh_free(bvh);
+  return 0;
 }
 
 /* Shadow ray (ray type 1): Material.cu:187-193 + disneyAnyHit :225-232, with the

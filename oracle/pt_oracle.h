@@ -126,6 +126,7 @@ void orc_trace_one(const OrcScene* sc, const float org[3], const float dir[3],
 /* nearest-hit query used by BVH-vs-brute-force tests. returns prim id or -1 */
 int orc_closest_hit(const OrcScene* sc, const float org[3], const float dir[3],
                     float tmin, float tmax, float* tHit);
+int orc_closest_hit_batch(const OrcScene* sc, const float* rays, int n, int32_t* outPrim, float* outT);
 
 /* ---- small pure functions exported for known-answer tests ---------------- */
 uint32_t orc_tea16(uint32_t v0, uint32_t v1);                 /* utils_device.h:8  */

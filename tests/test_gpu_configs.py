@@ -1,0 +1,227 @@
+"""GPU tests for the BASELINE.json configurations C4 / C5 at their full frame sizes, for the output side of the render
+entry (updateContent, progressive snapshots, renderScene, the CLI) and for sphere-light next-event estimation.
+
+Every case goes through the C ABI (ctypes) or through the C++ host entry; the CPU oracle is the checker."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import M, O, REPO, oracle_scene, rmse
+
+pytestmark = pytest.mark.gpu
+
+K = M._capi
+RMSE_TIGHT = 2e-6
+THREADS = min(32, os.cpu_count() or 1)
+
+
+def _render(ctx, seeds, counted=False):
+    ctx.accum_clear()
+    st = ctx.render_counted(seeds) if counted else ctx.render(seeds)
+    return ctx.accum_read(), st
+
+
+def test_c4_dining_standin_full_frame(gpu_ctx):
+    """BASELINE.json configs[3]: multi-mesh Disney room (6 transformed coffee sets in a box room, 1,006,864 triangles;
+    MinimalOptiX.cpp:284-296 camera), 1920x1080, tile split x8.  Oracle parity on a strip through the machines,
+    bit-identical 8-way tile reassembly, additive ray counters."""
+    W, H = 1920, 1080
+    hs = M.HostScene("dining_standin", W, H, iarg=6)
+    assert hs.sizes.nFaces > 1_000_000
+    seeds = M.launch_seeds(2)
+    gpu_ctx.load(hs)
+    whole, st = _render(gpu_ctx, seeds, counted=True)
+    assert st.samples == W * H * 2 and st.shadowRays > 0
+    y0, y1 = 496, 512
+    o, ost = oracle_scene(hs).render(seeds, region=(0, y0, W, y1), threads=THREADS)
+    assert rmse(whole[y0:y1] / 2, o[y0:y1] / 2) <= RMSE_TIGHT
+    assert o[y0:y1].max() > 0.05                                      # the strip is not empty
+    from minimaloptix_amd import dist as D
+    parts = np.zeros_like(whole).reshape(-1, 3)
+    rays = 0
+    try:
+        for r in range(8):
+            gpu_ctx.set_partition(r, 8)
+            a, s = _render(gpu_ctx, seeds, counted=True)
+            rays += s.rays
+            idx = D.tile_pixel_indices(W, H, r, 8)
+            parts[idx] = a.reshape(-1, 3)[idx]
+    finally:
+        gpu_ctx.set_partition(0, 1)
+    assert np.array_equal(parts.reshape(H, W, 3), whole) and rays == st.rays
+
+
+def test_c5_million_standin_4k_sample_split(gpu_ctx):
+    """BASELINE.json configs[4]: ~1.1 M-triangle glass torus knot + Disney sphere meshes + one SPHERE light,
+    3840x2160, sample split x8 (rank r renders launches i = r mod 8, then one sum).  Oracle parity on a strip, the
+    sum of the eight rank accumulators equals the 1-GPU frame up to float summation order, counters add up."""
+    W, H = 3840, 2160
+    hs = M.HostScene("million_standin", W, H, iarg=1000000)
+    assert hs.sizes.nFaces > 1_000_000 and hs.sizes.nLights == 1 and hs.sizes.nSpheres == 1
+    n = 8
+    seeds = M.launch_seeds(n)
+    gpu_ctx.load(hs)
+    whole, st = _render(gpu_ctx, seeds, counted=True)
+    assert st.samples == W * H * n and st.shadowRays > 0             # shadow rays towards the sphere light
+    y0, y1 = 1000, 1008
+    o, ost = oracle_scene(hs).render(seeds, region=(0, y0, W, y1), threads=THREADS)
+    assert rmse(whole[y0:y1] / n, o[y0:y1] / n) <= RMSE_TIGHT
+    total = np.zeros((H, W, 3), np.float64)
+    rays = 0
+    for r in range(8):
+        a, s = _render(gpu_ctx, seeds[r::8], counted=True)
+        total += a
+        rays += s.rays
+    assert rays == st.rays
+    assert np.abs(total / n - whole.astype(np.float64) / n).max() <= 2e-6
+    # the real reduction order (float32, rank order) stays inside the same bound
+    from minimaloptix_amd import dist as D
+    assert D.SAMPLE_SPLIT_TOL >= 2e-6
+
+
+def _sphere_light_scene(tmp_path):
+    d = tmp_path / "scenes" / "cornell"
+    d.mkdir(parents=True)
+    (d / "floor.obj").write_text("v -3 0 -2\nv -3 0 2\nv 3 0 2\nv 3 0 -2\nvn 0 1 0\nf 1//1 2//1 3//1 4//1\n"
+                                 "v -3 0 2\nv -3 3.4 2\nv 3 3.4 2\nv 3 0 2\nvn 0 0 -1\nf 5//2 6//2 7//2 8//2\n")
+    (d / "block.obj").write_text(
+        "v -0.5 0 -0.5\nv 0.5 0 -0.5\nv 0.5 0 0.5\nv -0.5 0 0.5\nv -0.5 0.8 -0.5\nv 0.5 0.8 -0.5\nv 0.5 0.8 0.5\nv -0.5 0.8 0.5\n"
+        "f 5 8 7 6\nf 1 2 6 5\nf 2 3 7 6\nf 3 4 8 7\nf 4 1 5 8\n")
+    (d / "pane.obj").write_text("v -1.5 0 1.0\nv -1.5 1.2 1.0\nv -0.6 1.2 1.4\nv -0.6 0 1.4\nf 1 2 3 4\n")
+    (d / "cornell.scene").write_text(
+        "material Floor\n{\n\tcolor 0.7 0.7 0.7\n\troughness 0.6\n}\n"
+        "material Block\n{\n\tcolor 0.8 0.3 0.2\n\troughness 0.3\n\tclearcoat 0.5\n}\n"
+        "material Pane\n{\n\tcolor 0.8 0.9 0.7\n\tbrdf 1\n}\n"
+        "mesh\n{\n\tfile floor.obj\n\tmaterial Floor\n}\n"
+        "mesh\n{\n\tfile block.obj\n\tmaterial Block\n}\n"
+        "mesh\n{\n\tfile pane.obj\n\tmaterial Pane\n}\n"
+        "light\n{\n\ttype Sphere\n\tposition 1.0 2.0 0.5\n\tradius 0.4\n\tnormal 0 -1 0\n\temission 30 30 30\n}\n"
+        "light\n{\n\ttype Quad\n\tposition -1 2.5 -1\n\tv1 -0.5 2.5 -1\n\tv2 -1 2.5 -0.5\n\temission 10 10 10\n}\n")
+    return str(tmp_path / "scenes") + "/"
+
+
+@pytest.mark.parametrize("variant", [0, 3])
+def test_sphere_light_next_event_estimation(gpu_ctx, tmp_path, variant):
+    """Material.cu:176-178: a sphere light is sampled at position + randInUnitSphere * radius (3 draws per attempt),
+    next to a quad light (2 draws); shadow rays pass a Disney glass pane (disneyAnyHit tint).  The sphere light's own
+    geometry gets correct bounds."""
+    hs = M.HostScene("file:cornell", 160, 120, base_folder=_sphere_light_scene(tmp_path))
+    assert [hs.flat()["lights"][i].shape for i in range(2)] == [K.LIGHT_SPHERE, K.LIGHT_QUAD]
+    seeds = M.launch_seeds(4, 3)
+    default = gpu_ctx.get_option("kernel_variant")
+    try:
+        gpu_ctx.set_option("kernel_variant", variant)
+        gpu_ctx.load(hs)
+        g, st = _render(gpu_ctx, seeds, counted=True)
+    finally:
+        gpu_ctx.set_option("kernel_variant", default)
+    o, ost = oracle_scene(hs).render(seeds)
+    assert rmse(g / 4, o / 4) <= RMSE_TIGHT
+    assert (st.primaryRays, st.bounceRays, st.shadowRays) == (ost.primaryRays, ost.bounceRays, ost.shadowRays)
+    # the sphere light matters: without it the image is much darker
+    d = hs.to_dict(); d["lights"] = d["lights"][1:]
+    dark, _ = O.Scene(d).render(seeds)
+    assert (o.mean() - dark.mean()) / 4 > 0.02
+
+
+def test_resolve_rgb8_is_update_content(gpu_ctx):
+    """MinimalOptiX::updateContent (MinimalOptiX.cpp:43-66): clamp(accu / n, 0, 1) -> QColor -> RGB888 with the rows
+    flipped, optionally clearing the accumulator; done on the device by k_resolve_rgb8."""
+    hs = M.HostScene("spheres", 200, 120, farg=0.5)
+    spp = 5
+    seeds = M.launch_seeds(spp)
+    gpu_ctx.load(hs)
+    acc, _ = _render(gpu_ctx, seeds)
+    o, _ = oracle_scene(hs).render(seeds)
+    img = gpu_ctx.resolve_rgb8(spp, clear=False)
+    assert img.shape == (120, 200, 3) and img.dtype == np.uint8
+    assert np.array_equal(img, O.rgb8_from_accum(acc, spp))           # bit-exact bytes from the same accumulator
+    ref = O.rgb8_from_accum(o, spp)                                    # the oracle's own accumulator: differs by float association only
+    diff = np.abs(img.astype(np.int32) - ref.astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+    assert np.array_equal(gpu_ctx.accum_read(), acc)                   # clearBuffer = false leaves accuBuffer alone
+    # other divisors, over-range values (clamp) and the clearing variant
+    assert np.array_equal(gpu_ctx.resolve_rgb8(2.0), O.rgb8_from_accum(acc, 2.0))
+    img2 = gpu_ctx.resolve_rgb8(spp, clear=True)
+    assert np.array_equal(img2, img)
+    assert not gpu_ctx.accum_read().any()                              # MinimalOptiX.cpp:53-57
+
+
+def _read_png(path):
+    w, h = C.c_int32(), C.c_int32()
+    L = K.host_lib()
+    assert L.mohost_read_image(path.encode(), C.byref(w), C.byref(h), None, 0) == K.MOPTIX_OK, L.mohost_last_error()
+    px = np.zeros((h.value, w.value, 3), np.uint8)
+    assert L.mohost_read_image(path.encode(), C.byref(w), C.byref(h), px.ctypes.data_as(C.POINTER(C.c_uint8)), px.size) == K.MOPTIX_OK
+    return px
+
+
+def test_render_scene_entry_with_progressive_snapshots(gpu_ctx, tmp_path):
+    """MinimalOptiX::renderScene(autoSave=true, prefix) (MinimalOptiX.cpp:540-560) through the C++ host class
+    (mohost_render_scene): snapshots <prefix>_<k>.png at k = 1, 2, 4, ... and <prefix>.png at the end, each equal to
+    updateContent of the first k launches."""
+    W, H, spp = 320, 180, 6
+    out = str(tmp_path)
+    canvas = np.zeros((H, W, 3), np.uint8)
+    res = K.RenderResult()
+    rc = K.host_lib().mohost_render_scene(0, 1, M.scenes_dir().encode(), W, H, spp, 0, 1, b"coffee", out.encode(),
+                                          canvas.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(res))
+    assert rc == K.MOPTIX_OK, K.host_lib().mohost_last_error()
+    assert res.nFaces == 168193 and res.nNodes > 0 and res.renderMs > 0 and res.bvhBuildMs > 0
+    files = sorted(os.listdir(out))
+    assert files == ["coffee.png", "coffee_1.png", "coffee_2.png", "coffee_4.png"]
+    hs = M.HostScene("file:coffee", W, H)
+    seeds = M.launch_seeds(spp)
+    gpu_ctx.load(hs)
+    gpu_ctx.accum_clear()
+    done = 0
+    for k in (1, 2, 4, 6):
+        gpu_ctx.render(seeds[done:k]); done = k
+        want = gpu_ctx.resolve_rgb8(k)
+        name = "coffee.png" if k == spp else "coffee_%d.png" % k
+        assert np.array_equal(_read_png(os.path.join(out, name)), want), name
+    assert np.array_equal(canvas, want)
+    o, _ = oracle_scene(hs).render(seeds)
+    diff = np.abs(canvas.astype(np.int32) - O.rgb8_from_accum(o, spp).astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+
+
+def test_cli_renders_a_frame(tmp_path):
+    """The headless replacement of the reference's application (main.cpp:4-10): moptix_render writes the canvas."""
+    exe = os.path.join(REPO, "minimaloptix_amd", "lib", "moptix_render")
+    assert os.path.exists(exe), "run make host"
+    r = subprocess.run([exe, "--scene", "spheres", "--spp", "3", "--width", "160", "--height", "90", "--out", "cli",
+                        "--outdir", str(tmp_path), "--scenes", M.scenes_dir()], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    img = _read_png(os.path.join(str(tmp_path), "cli.png"))
+    hs = M.HostScene("spheres", 160, 90, farg=0.5)
+    seeds = M.launch_seeds(3)
+    o, _ = oracle_scene(hs).render(seeds)
+    diff = np.abs(img.astype(np.int32) - O.rgb8_from_accum(o, 3).astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+
+
+def test_watchdog_reports_and_leaves_the_accumulator_alone(gpu_ctx):
+    """The persistent kernel gives up after `watchdog_ms` of wall-clock time instead of hanging the GPU.  A pass that
+    was cut short is not reduced into accuBuffer, the error surfaces at the sync, and the context stays usable."""
+    hs = M.HostScene("file:coffee", 1920, 1080)
+    seeds = M.launch_seeds(16)
+    gpu_ctx.load(hs)
+    gpu_ctx.accum_clear()
+    default = gpu_ctx.get_option("watchdog_ms")
+    try:
+        gpu_ctx.set_option("watchdog_ms", 1)
+        with pytest.raises(M.MoptixError) as e:
+            gpu_ctx.render(seeds)
+        assert "watchdog" in str(e.value)
+    finally:
+        gpu_ctx.set_option("watchdog_ms", default)
+    assert not gpu_ctx.accum_read().any()
+    small = M.HostScene("file:coffee", 96, 54)
+    gpu_ctx.load(small)
+    g, _ = _render(gpu_ctx, seeds[:2])
+    o, _ = oracle_scene(small).render(seeds[:2])
+    assert rmse(g / 2, o / 2) <= RMSE_TIGHT

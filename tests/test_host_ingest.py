@@ -179,3 +179,15 @@ def test_sphere_light_scene_matches_oracle(tmp_path):
     assert (cnt["primaryRays"], cnt["bounceRays"], cnt["shadowRays"]) == (st.primaryRays, st.bounceRays, st.shadowRays)
     assert st.shadowRays > 0 and rmse(got, ref) / len(seeds) < 1e-5
     assert ref.max() > 0.5                                                   # the light reaches the floor
+
+
+def test_face_index_past_the_last_vertex_is_an_error(tmp_path):
+    """A face that references a vertex the file never defines: the reference reads attrib.vertices out of bounds
+    (MinimalOptiX.cpp:430-433); here scene ingest reports it."""
+    d = tmp_path / "cornell"
+    d.mkdir()
+    (d / "a.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\n")
+    (d / "cornell.scene").write_text("material M\n{\n\tcolor 1 1 1\n}\nmesh\n{\n\tfile a.obj\n\tmaterial M\n}\n")
+    with pytest.raises(M.MoptixError) as e:
+        M.HostScene("file:cornell", 32, 32, base_folder=str(tmp_path) + "/")
+    assert "references vertex 7 of 3" in str(e.value)
