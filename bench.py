@@ -30,20 +30,26 @@ def algorithmic_bytes(st, pixels):
     return 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * pixels
 
 
-def cpu_baseline(width, height, n_launches):
-    """The CPU oracle (kind "port": this repo's plain-C restatement; the reference has no CPU path),
-    all host cores, on a bounded sample of the same workload: the full frame for the first
-    `n_launches` of the 256 launch seeds."""
-    from oracle import oracle as O
+def cpu_baseline(width, height, target_s):
+    """north_star / BASELINE.md section 2: "a CPU build of the same megakernel" -- the per-lane path code of
+    minimaloptix_amd/csrc/pt_path.h and the same LBVH (tests/hostsim, test infrastructure; kind "port": the reference
+    has no CPU path), compiled with g++ -O3 -fopenmp, all host cores, same seeds.  Bounded sample: whole frames for
+    the first n of the 256 launch seeds, n chosen from the first launch so that the leg takes about `target_s`
+    seconds.  The LBVH build (single thread) is excluded from the rate and reported next to it."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from common import hostsim_render
     import minimaloptix_amd as M
     hs = M.HostScene("file:coffee", width, height)
-    sc = O.Scene(hs.to_dict())
-    seeds = M.launch_seeds(n_launches)
-    t0 = time.time()
-    _, st = sc.render(seeds)
-    dt = time.time() - t0
-    return {"value": round(st.rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": int(O.lib().orc_num_threads()), "kind": "port",
-            "sample": "coffee %dx%d, %d of 256 launches (%.1f s, %d rays, BVH build included)" % (width, height, n_launches, dt, st.rays)}
+    seeds = M.launch_seeds(256)
+    _, c = hostsim_render(hs, seeds[:1])
+    rays, secs, build_s, n = c["primaryRays"] + c["bounceRays"] + c["shadowRays"], c["render_s"], c["build_s"], 1
+    more = max(0, min(255, int(target_s / max(secs, 1e-3)) - 1))
+    if more:
+        _, c = hostsim_render(hs, seeds[1:1 + more])
+        rays += c["primaryRays"] + c["bounceRays"] + c["shadowRays"]; secs += c["render_s"]; n += more
+    return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": int(c["threads"]), "kind": "port",
+            "sample": "CPU build of the same megakernel (pt_path.h + same LBVH, g++ -O3 -fopenmp): coffee %dx%d, %d of 256 "
+                      "launches, %.1f s, %d rays; LBVH build %.2f s on one thread excluded" % (width, height, n, secs, rays, build_s)}
 
 
 def read_traffic(repo):
@@ -66,7 +72,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--scene", default="file:coffee")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-launches", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
     a = ap.parse_args()
 
     import torch
@@ -214,7 +220,7 @@ def main():
                          "bytes_per_ray": round(my_bytes / max(1, my_rays), 1), "reduce_ms_total": round(reduce_ms, 3)},
         }
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(W, H, a.cpu_launches)
+            out["cpu_baseline"] = cpu_baseline(W, H, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -44,6 +44,8 @@ def hostsim_lib():
         L = C.CDLL(path)
         L.hostsim_render.argtypes = [C.POINTER(HostsimScene), C.c_int, C.POINTER(C.c_int32), C.c_int,
                                      C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+        L.hostsim_render_timed.argtypes = [C.POINTER(HostsimScene), C.c_int, C.POINTER(C.c_int32), C.c_int,
+                                           C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.hostsim_build_bvh.argtypes = [C.POINTER(HostsimScene), C.c_int, C.POINTER(HostsimBvhOut)]
         _hostsim = L
     return _hostsim
@@ -84,10 +86,13 @@ def hostsim_render(hs, seeds, leaf_size=4, accum=None):
     if accum is None:
         accum = np.zeros((hs.height, hs.width, 3), np.float32)
     cnt = (C.c_uint64 * 9)()
-    rc = hostsim_lib().hostsim_render(C.byref(s), leaf_size, seeds.ctypes.data_as(C.POINTER(C.c_int32)), len(seeds),
-                                      accum.ctypes.data_as(C.POINTER(C.c_float)), cnt)
+    timing = (C.c_double * 3)()
+    rc = hostsim_lib().hostsim_render_timed(C.byref(s), leaf_size, seeds.ctypes.data_as(C.POINTER(C.c_int32)), len(seeds),
+                                            accum.ctypes.data_as(C.POINTER(C.c_float)), cnt, timing)
     assert rc == 0
-    return accum, dict(zip(HOSTSIM_COUNTERS, [int(x) for x in cnt]))
+    out = dict(zip(HOSTSIM_COUNTERS, [int(x) for x in cnt]))
+    out.update(build_s=timing[0], render_s=timing[1], threads=int(timing[2]))
+    return accum, out
 
 
 def hostsim_bvh(hs, leaf_size=4):

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <omp.h>
 #include "../../minimaloptix_amd/csrc/pt_path.h"
 #include "../../minimaloptix_amd/csrc/pt_lbvh.h"
 #include "../../minimaloptix_amd/csrc/pt_upload.h"
@@ -285,8 +286,13 @@ int hostsim_build_bvh(const hostsim_scene* s, int leafSize, hostsim_bvh_out* out
 }
 
 // counters: samples, primary, bounce, shadow, nodeFetches, triTests, closestHits, lightLoads, analyticTests
-int hostsim_render(const hostsim_scene* s, int leafSize, const int32_t* seeds, int nSeeds, float* accum, uint64_t counters[9]) {
+// timing (may be NULL): [0] seconds of scene set-up + LBVH build (single thread), [1] seconds of rendering (all OpenMP
+// threads), [2] the number of threads used -- bench.py's cpu_baseline: "a CPU build of the same megakernel", BVH build
+// excluded from the rate and reported separately.
+int hostsim_render_timed(const hostsim_scene* s, int leafSize, const int32_t* seeds, int nSeeds, float* accum, uint64_t counters[9], double timing[3]) {
+  const double t0 = omp_get_wtime();
   HostScene hs; make_scene(*s, leafSize, hs);
+  const double t1 = omp_get_wtime();
   const SceneView& sc = hs.view;
   uint64_t tot[9] = { 0 };
   const int nPix = sc.width * sc.height;
@@ -327,7 +333,12 @@ int hostsim_render(const hostsim_scene* s, int leafSize, const int32_t* seeds, i
     for (int i = 0; i < 9; i++) tot[i] += loc[i];
   }
   if (counters) for (int i = 0; i < 9; i++) counters[i] = tot[i];
+  if (timing) { timing[0] = t1 - t0; timing[1] = omp_get_wtime() - t1; timing[2] = (double)omp_get_max_threads(); }
   return 0;
+}
+
+int hostsim_render(const hostsim_scene* s, int leafSize, const int32_t* seeds, int nSeeds, float* accum, uint64_t counters[9]) {
+  return hostsim_render_timed(s, leafSize, seeds, nSeeds, accum, counters, nullptr);
 }
 
 }  // extern "C"
