@@ -30,7 +30,8 @@ const char* mohost_last_error(void);
  *       "file:<name>"  coffee|bedroom|diningroom|stormtrooper|spaceship|cornell|hyperion|dragon
  *                      (setupScene(name) + camera of MinimalOptiX.cpp:258-353; baseFolder = "scenes/")
  *       "random_spheres" (iarg = nSpheres; setUpVideo, MinimalOptiX.cpp:607-759)
- *       "cornell_quads" | "dining_standin" (iarg = copies) | "million_standin" (iarg = triangles) */
+ *       "cornell_quads" | "dining_standin" (iarg = copies) | "million_standin" (iarg = triangles)
+ *       "coffee_pot_standin" (coffee + a lathe stand-in for the missing glass pot Mesh010.obj) */
 int mohost_scene_build(const char* kind, const char* baseFolder, uint32_t width, uint32_t height,
                        int32_t iarg, float farg, int skipMissing, mohost_scene* out);
 void mohost_scene_free(mohost_scene s);

@@ -56,7 +56,21 @@ PT_HD v3 cross(v3 a, v3 b) {                                                    
   return mk3(fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x)));
 }
 PT_HD float length(v3 a) { return __builtin_sqrtf(dot(a, a)); }
+#if defined(PT_EXPERIMENT_RSQ_ERR)
+// Experiment (tests/hostsim only, never in the product build): the reference is compiled with -use_fast_math, where
+// 1/sqrtf is rsqrt.approx (max relative error 2^-22.4).  This models that error as a deterministic pseudo-random
+// relative perturbation of the reciprocal length, to measure how far the image moves ("coffee.png pin").
+PT_HD v3 normalize(v3 a) {
+  const float d = dot(a, a);
+  float inv = 1.0f / __builtin_sqrtf(d);
+  uint32_t h = (uint32_t)__builtin_bit_cast(int32_t, d) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+  const float u = (float)(h >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;           // [-1, 1)
+  inv = inv * (1.0f + u * (float)(PT_EXPERIMENT_RSQ_ERR));
+  return a * inv;
+}
+#else
 PT_HD v3 normalize(v3 a) { float inv = 1.0f / __builtin_sqrtf(dot(a, a)); return a * inv; }
+#endif
 PT_HD v3 ray_at(v3 o, v3 d, float t) { return mk3(fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z)); }  // AC7
 PT_HD float lerp(float a, float b, float t) { return a + t * (b - a); }
 PT_HD v3 lerp(v3 a, v3 b, float t) { return a + (b - a) * t; }

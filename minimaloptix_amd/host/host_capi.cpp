@@ -27,6 +27,7 @@ int mohost_scene_build(const char* kind, const char* baseFolder, uint32_t width,
     else if (k == "random_spheres") buildRandomSpheresScene(s->desc, iarg, width, height);
     else if (k == "cornell_quads") buildCornellQuadsScene(s->desc, width, height);
     else if (k == "dining_standin") buildDiningStandInScene(s->desc, base, iarg, width, height);
+    else if (k == "coffee_pot_standin") buildCoffeePotStandInScene(s->desc, base, width, height);
     else if (k == "million_standin") buildProceduralMillionScene(s->desc, iarg, width, height);
     else { delete s; g_err = "unknown scene kind: " + k; return MOPTIX_ERR_INVALID; }
     *out = s;

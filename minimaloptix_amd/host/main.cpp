@@ -10,7 +10,7 @@
 
 static void usage() {
   fprintf(stderr,
-          "usage: moptix_render [--scene spheres|coffee|cornell_quads|random_spheres|random_spheres_256|dining_standin|million_standin|<file scene>]\n"
+          "usage: moptix_render [--scene spheres|coffee|cornell_quads|random_spheres|random_spheres_256|dining_standin|million_standin|coffee_pot_standin|<file scene>]\n"
           "                     [--spp N] [--width W] [--height H] [--seed S] [--scenes DIR/] [--out PREFIX] [--outdir DIR]\n"
           "                     [--autosave] [--device D] [--random-seeds] [--strict-missing]\n");
 }
@@ -55,6 +55,7 @@ int main(int argc, char** argv) {
     else if (scene == "cornell_quads") app.sceneId = MinimalOptiX::SCENE_CORNELL_QUADS;
     else if (scene == "dining_standin") app.sceneId = MinimalOptiX::SCENE_DINING_STANDIN;
     else if (scene == "million_standin") app.sceneId = MinimalOptiX::SCENE_MILLION_STANDIN;
+    else if (scene == "coffee_pot_standin") app.sceneId = MinimalOptiX::SCENE_COFFEE_POT_STANDIN;
     else { usage(); return 2; }
     app.renderScene(autosave, prefix);
     if (!autosave) app.saveCurrentFrame(false, prefix);

@@ -59,6 +59,7 @@ void MinimalOptiX::setupScene() {
     case SCENE_RANDOM_SPHERES_500: buildRandomSpheresScene(scene, 497, fixedWidth, fixedHeight); break;
     case SCENE_DINING_STANDIN: buildDiningStandInScene(scene, baseSceneFolder, 6, fixedWidth, fixedHeight); break;
     case SCENE_MILLION_STANDIN: buildProceduralMillionScene(scene, 1000000, fixedWidth, fixedHeight); break;
+    case SCENE_COFFEE_POT_STANDIN: buildCoffeePotStandInScene(scene, baseSceneFolder, fixedWidth, fixedHeight); break;
   }
   scene.params.rayMaxDepth = rayMaxDepth; scene.params.rayMinIntensity = rayMinIntensity; scene.params.rayEpsilonT = rayEpsilonT;
   aabb = scene.aabb; nVertices = scene.nVertices; nFaces = scene.nFaces;

@@ -18,7 +18,8 @@ public:
     SCENE_SPHERES, SCENE_COFFEE, SCENE_BEDROOM, SCENE_DININGROOM, SCENE_STORMTROOPER,
     SCENE_SPACESHIP, SCENE_CORNELL, SCENE_HYPERION, SCENE_DRAGON, SCENE_SPHERES_VIDEO,
     // additions (BASELINE.json configs whose assets the reference does not ship)
-    SCENE_CORNELL_QUADS, SCENE_RANDOM_SPHERES_500, SCENE_DINING_STANDIN, SCENE_MILLION_STANDIN
+    SCENE_CORNELL_QUADS, SCENE_RANDOM_SPHERES_500, SCENE_DINING_STANDIN, SCENE_MILLION_STANDIN,
+    SCENE_COFFEE_POT_STANDIN
   };
   enum RayType { RAY_TYPE_RADIANCE, RAY_TYPE_SHADOW };
 

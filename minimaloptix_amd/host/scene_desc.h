@@ -82,6 +82,8 @@ void buildRandomSpheresScene(SceneDesc& s, int nSpheres, uint32_t width, uint32_
 void buildCornellQuadsScene(SceneDesc& s, uint32_t width, uint32_t height);
 // BASELINE config 4 stand-in: box room + K transformed copies of the coffee meshes, Disney mix
 void buildDiningStandInScene(SceneDesc& s, const std::string& baseSceneFolder, int copies, uint32_t width, uint32_t height);
+// coffee scene + a lathe stand-in for its glass pot (Mesh010.obj is missing from the reference checkout)
+void buildCoffeePotStandInScene(SceneDesc& s, const std::string& baseSceneFolder, uint32_t width, uint32_t height);
 // BASELINE config 5 stand-in: ~nTris-triangle procedural displaced torus knot (glass) + floor + sphere light
 void buildProceduralMillionScene(SceneDesc& s, int nTrisTarget, uint32_t width, uint32_t height);
 

@@ -142,6 +142,54 @@ void buildDiningStandInScene(SceneDesc& s, const std::string& baseSceneFolder, i
 }
 
 // ------------------------------------------------------------------------------------------
+// coffee + a stand-in for its glass pot.  coffee.scene's mesh entry "Mesh010.obj / material Glass" names a file the
+// reference checkout does not ship (.MISSING_LARGE_BLOBS:1), so the shipped scene never runs the Disney GLASS branch
+// (Material.cu:134-168) or a shadow ray through glass (Material.cu:226-227).  The stand-in is a thin-walled lathe body
+// (outer wall, rim, inner wall, double bottom; 96 segments, 8,256 triangles) in the pot's place between the base plate
+// (Mesh012, top at y = 0.025) and the lid (Mesh008, y = 0.114), radius 0.072 like the metal band Mesh015, with smooth
+// vertex normals and the scene file's Glass material (color 1 1 1, brdf 1).  It lies inside the room, so the scene
+// box and with it the camera (MinimalOptiX.cpp:263-267) are those of the shipped scene.
+void buildCoffeePotStandInScene(SceneDesc& s, const std::string& baseSceneFolder, uint32_t width, uint32_t height) {
+  buildFileScene(s, baseSceneFolder, "coffee", width, height, true);
+  s.name = "coffee_pot_standin";
+  static const double prof[12][2] = { { 0.0, 0.028 }, { 0.066, 0.028 }, { 0.071, 0.036 }, { 0.072, 0.075 }, { 0.068, 0.105 }, { 0.064, 0.114 },
+                                      { 0.061, 0.114 }, { 0.065, 0.105 }, { 0.069, 0.075 }, { 0.068, 0.038 }, { 0.063, 0.031 }, { 0.0, 0.031 } };
+  std::vector<double> pr, py;
+  for (int k = 0; k + 1 < 12; k++)
+    for (int j = 0; j < 4; j++) { const double t = j / 4.0; pr.push_back(prof[k][0] + (prof[k + 1][0] - prof[k][0]) * t); py.push_back(prof[k][1] + (prof[k + 1][1] - prof[k][1]) * t); }
+  pr.push_back(prof[11][0]); py.push_back(prof[11][1]);
+  const int n = (int)pr.size(), seg = 96;
+  std::vector<double> nr(n), ny(n);                       // profile normal = tangent rotated by -90 degrees (outwards along the list)
+  for (int i = 0; i < n; i++) {
+    const int a = i > 0 ? i - 1 : i, b = i + 1 < n ? i + 1 : i;
+    const double tr = (pr[b] - pr[a]) / (b - a), ty = (py[b] - py[a]) / (b - a), l = sqrt(tr * tr + ty * ty);
+    nr[i] = ty / l; ny[i] = -tr / l;
+  }
+  moptix_disney_params glass = disneyDefaults(); glass.brdfType = MOPTIX_BRDF_GLASS; glass.color = { 1.f, 1.f, 1.f };   // coffee.scene:19-23
+  MeshDesc pot; pot.source = "pot_standin(Mesh010.obj)"; pot.matId = s.addMaterial(disneyMaterial(glass));
+  const double twoPi = 6.283185307179586;
+  for (int j = 0; j < seg; j++) {
+    const double a = twoPi * j / seg, ca = cos(a), sa = sin(a);
+    for (int i = 0; i < n; i++) {
+      pot.positions.push_back((float)(pr[i] * ca)); pot.positions.push_back((float)py[i]); pot.positions.push_back((float)(pr[i] * sa));
+      pot.normals.push_back((float)(nr[i] * ca)); pot.normals.push_back((float)ny[i]); pot.normals.push_back((float)(nr[i] * sa));
+    }
+  }
+  auto tri = [&](int a, int b, int c) { for (int v : { a, b, c }) { pot.vIdx.push_back(v); pot.nIdx.push_back(v); pot.tIdx.push_back(-1); } };
+  for (int j = 0; j < seg; j++) {
+    const int j1 = (j + 1) % seg;
+    for (int i = 0; i + 1 < n; i++) {
+      const int a = j * n + i, b = j * n + i + 1, c = j1 * n + i + 1, d = j1 * n + i;
+      if (pr[i] == 0.0) tri(a, c, b);
+      else if (pr[i + 1] == 0.0) tri(a, d, b);
+      else { tri(a, d, c); tri(a, c, b); }
+    }
+  }
+  includeMesh(s, pot);
+  s.meshes.push_back(std::move(pot));
+}
+
+// ------------------------------------------------------------------------------------------
 // Config 5: displaced (3,2) torus-knot tube of ~nTrisTarget triangles (glass), three Disney
 // tessellated spheres, a floor, one sphere light.  bg 0.5 and the dragon camera
 // (MinimalOptiX.cpp:336-353).

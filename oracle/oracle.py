@@ -132,6 +132,8 @@ def lib():
         L.orc_closest_hit.argtypes = [C.POINTER(OrcScene), f3, f3, C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.orc_closest_hit_batch.restype = C.c_int
         L.orc_closest_hit_batch.argtypes = [C.POINTER(OrcScene), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+        L.orc_set_option.restype = C.c_int
+        L.orc_set_option.argtypes = [C.c_char_p, C.c_int]
         L.orc_move_sphere.restype = None
         L.orc_move_sphere.argtypes = [f3, C.c_float, f3, C.c_float]
         L.orc_tex2d.argtypes = [C.POINTER(OrcTexture), C.c_float, C.c_float, C.c_float * 4]
@@ -139,6 +141,12 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         _lib = L
     return _lib
+
+
+def set_option(name, value):
+    """Analysis switches of the oracle ("disney_binary64": evaluate the Disney BRDF in binary64)."""
+    if lib().orc_set_option(name.encode(), int(value)) != 0:
+        raise ValueError(name)
 
 
 def launch_seeds(n, base_seed=0, first=0):

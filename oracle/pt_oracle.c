@@ -362,6 +362,107 @@ static f3 disney_eval(const OrcMaterial* m, f3 baseColor, f3 N, f3 L, f3 V, f3 H
   return adds3(add3(diffuse, spec), cc);
 }
 
+/* ---------------------------------------------------------------------------------------------------------
+ * "Exact arithmetic" variant of disneySample / disneyPdf / disneyEval: the same formulas (disney.h:9-91)
+ * evaluated in binary64.  NOT the parity contract (the GPU computes in binary32, as the reference does); it
+ * exists to tell apart, when the oracle is compared with the reference's demo images, what the FORMULAS give
+ * from what binary32 rounding adds.  coffee.scene's Plastic_Orange has roughness 0.001, i.e. alpha^2 = 1e-6:
+ * 1 + (alpha^2 - 1) cos^2(theta_h) is then computed from a cosine that is only known to 6e-8, and the
+ * brightness of a light's reflection in that material depends on how every operation before it rounded
+ * (DESIGN.md "coffee.png pin").  Enabled with orc_set_option("disney_binary64", 1). */
+typedef struct { double x, y, z; } d3;
+static inline d3 dmk(double x, double y, double z) { d3 r = { x, y, z }; return r; }
+static inline d3 d_of(f3 a) { return dmk(a.x, a.y, a.z); }
+static inline f3 f_of(d3 a) { return mk3((float)a.x, (float)a.y, (float)a.z); }
+static inline d3 dadd(d3 a, d3 b) { return dmk(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline d3 dsub(d3 a, d3 b) { return dmk(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline d3 dscl(d3 a, double s) { return dmk(a.x * s, a.y * s, a.z * s); }
+static inline double ddot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline d3 dcross(d3 a, d3 b) { return dmk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline d3 dnorm(d3 a) { return dscl(a, 1.0 / sqrt(ddot(a, a))); }
+static inline double dlerp(double a, double b, double t) { return a + t * (b - a); }
+static inline double dsqr(double x) { return x * x; }
+static const double D_PI = (double)ORC_PI;
+typedef struct { d3 tangent, binormal, normal; } OnbD;
+static OnbD onb_make_d(d3 n) {
+  OnbD o; o.normal = n;
+  if (fabs(n.x) > fabs(n.z)) o.binormal = dmk(-n.y, n.x, 0.0); else o.binormal = dmk(0.0, -n.z, n.y);
+  o.binormal = dnorm(o.binormal);
+  o.tangent = dcross(o.binormal, o.normal);
+  return o;
+}
+static d3 onb_inverse_d(const OnbD* o, d3 p) { return dadd(dadd(dscl(o->tangent, p.x), dscl(o->binormal, p.y)), dscl(o->normal, p.z)); }
+static double schlick_d(double u) { double m = fmin(fmax(1.0 - u, 0.0), 1.0); double m2 = m * m; return m2 * m2 * m; }
+static double GTR1_d(double c, double a) { if (a >= 1.0) return 1.0 / D_PI; double a2 = a * a; return (a2 - 1.0) / (D_PI * log(a2) * (1.0 + (a2 - 1.0) * c * c)); }
+static double GTR2_d(double c, double a) { double a2 = a * a, t = 1.0 + (a2 - 1.0) * c * c; return a2 / (D_PI * t * t); }
+static double smithG_d(double nv, double ag) { double a = ag * ag, b = nv * nv; return 1.0 / (nv + sqrt(a + b - a * b)); }
+static double smithGA_d(double nv, double vx, double vy, double ax, double ay) { return 1.0 / (nv + sqrt(dsqr(vx * ax) + dsqr(vy * ay) + dsqr(nv))); }
+/* same random draws, in the same order, as disney_sample */
+static void disney_sample_d(int32_t* seed, const OrcMaterial* m, d3 N, d3 V, d3* L, d3* H) {
+  double diffuseRatio = 0.5 * (1.0 - (double)m->metallic);
+  OnbD onb = onb_make_d(N);
+  if ((double)orc_rand(seed) < diffuseRatio) {
+    double u1 = orc_rand(seed), u2 = orc_rand(seed);
+    double r = sqrt(u1), phi = 2.0 * D_PI * u2;
+    d3 l = dmk(r * cos(phi), r * sin(phi), 0.0);
+    l.z = sqrt(fmax(0.0, 1.0 - l.x * l.x - l.y * l.y));
+    *L = dnorm(onb_inverse_d(&onb, l));
+    *H = dnorm(dadd(*L, V));
+  } else {
+    double a = fmax(0.001, (double)m->roughness);
+    double phi = (double)orc_rand(seed) * 2.0 * D_PI;
+    double random = orc_rand(seed);
+    double cosTheta = sqrt((1.0 - random) / (1.0 + (a * a - 1.0) * random));
+    double sinTheta = sqrt(1.0 - cosTheta * cosTheta);
+    d3 h = onb_inverse_d(&onb, dmk(sinTheta * cos(phi), sinTheta * sin(phi), cosTheta));
+    *L = dnorm(dsub(dscl(h, 2.0 * ddot(V, h)), V));
+    *H = dnorm(h);
+  }
+}
+static double disney_pdf_d(const OrcMaterial* m, d3 N, d3 L, d3 H) {
+  double diffuseRatio = 0.5 * (1.0 - (double)m->metallic);
+  double c = fabs(ddot(N, H));
+  double pdfH = dlerp(GTR1_d(c, dlerp(0.1, 0.001, m->clearcoatGloss)) * c, GTR2_d(c, fmax(0.001, (double)m->roughness)) * c, 1.0 / (1.0 + (double)m->clearcoat));
+  return diffuseRatio * fabs(ddot(N, L)) / D_PI + (1.0 - diffuseRatio) * pdfH / (4.0 * fabs(ddot(L, H)));
+}
+static d3 disney_eval_d(const OrcMaterial* m, f3 baseColor, d3 N, d3 L, d3 V, d3 H) {
+  OnbD onb = onb_make_d(N);
+  double NdotL = ddot(N, L), NdotV = ddot(N, V), NdotH = ddot(N, H), LdotH = ddot(L, H);
+  d3 Cdlin = dmk(pow(baseColor.x, (double)2.2f), pow(baseColor.y, (double)2.2f), pow(baseColor.z, (double)2.2f));
+  double Cdlum = 0.3 * Cdlin.x + 0.6 * Cdlin.y + 0.1 * Cdlin.z;
+  d3 one = dmk(1, 1, 1);
+  d3 Ctint = Cdlum > 0 ? dscl(Cdlin, 1.0 / Cdlum) : one;
+  d3 t0 = dscl(dadd(one, dscl(dsub(Ctint, one), m->specularTint)), (double)m->specular * 0.08);
+  d3 Cspec0 = dadd(t0, dscl(dsub(Cdlin, t0), m->metallic));
+  d3 Csheen = dadd(one, dscl(dsub(Ctint, one), m->sheenTint));
+  double FL = schlick_d(NdotL), FV = schlick_d(NdotV), r = m->roughness;
+  double Fd90 = 0.5 + 2.0 * LdotH * LdotH * r;
+  double Fd = dlerp(1.0, Fd90, FL) * dlerp(1.0, Fd90, FV);
+  double Fss90 = LdotH * LdotH * r;
+  double Fss = dlerp(1.0, Fss90, FL) * dlerp(1.0, Fss90, FV);
+  double ss = 1.25 * (Fss * (1.0 / (NdotL + NdotV) - 0.5) + 0.5);
+  double aspect = sqrt(1.0 - (double)m->anisotropic * 0.9);
+  double ax = fmax(.001, r * r / aspect), ay = fmax(.001, r * r * aspect);
+  d3 X = dnorm(onb.tangent), Y = dnorm(dcross(N, X));
+  double Ds = 1.0 / (D_PI * ax * ay * dsqr(dsqr(ddot(H, X) / ax) + dsqr(ddot(H, Y) / ay) + NdotH * NdotH));
+  double FH = schlick_d(LdotH);
+  d3 Fs = dadd(Cspec0, dscl(dsub(one, Cspec0), FH));
+  double Gs = smithGA_d(NdotL, ddot(L, X), ddot(L, Y), ax, ay) * smithGA_d(NdotV, ddot(V, X), ddot(V, Y), ax, ay);
+  d3 Fsheen = dscl(Csheen, FH * (double)m->sheen);
+  double Dr = GTR1_d(NdotH, dlerp(0.1, 0.001, m->clearcoatGloss));
+  double Fr = dlerp(0.04, 1.0, FH);
+  double Gr = smithG_d(NdotL, 0.25) * smithG_d(NdotV, 0.25);
+  d3 diffuse = dscl(dadd(dscl(Cdlin, (1.0 / D_PI) * dlerp(Fd, ss, m->subsurface)), Fsheen), 1.0 - (double)m->metallic);
+  d3 spec = dscl(Fs, Gs * Ds);
+  double cc = 0.25 * (double)m->clearcoat * Gr * Fr * Dr;
+  return dmk(diffuse.x + spec.x + cc, diffuse.y + spec.y + cc, diffuse.z + spec.z + cc);
+}
+static int g_disney_binary64 = 0;
+int orc_set_option(const char* name, int value) {
+  if (!strcmp(name, "disney_binary64")) { g_disney_binary64 = value != 0; return 0; }
+  return -1;
+}
+
 float orc_disney_pdf(const OrcMaterial* m, const float N[3], const float L[3], const float V[3], const float H[3]) {
   return disney_pdf(m, ld3(N), ld3(L), ld3(V), ld3(H));
 }
@@ -762,6 +863,7 @@ static void prog_disney(Ctx* cx, const OrcMaterial* m, f3 d, const Hit* h, Paylo
     baseColor = mk3(tc[0], tc[1], tc[2]);
   }
   if (m->brdfType == ORC_BRDF_GLASS) { glass_body(cx, 1.45f, baseColor, d, h, p); return; }
+  const d3 Nd = dnorm(d_of(N)), Vd = dnorm(d_of(V));   /* binary64 analysis mode: unit vectors to 1e-16, not 6e-8 */
 
   f3 direct = mk3(0.f, 0.f, 0.f);
   for (int32_t i = 0; i < sc->nLights; ++i) {
@@ -785,8 +887,10 @@ static void prog_disney(Ctx* cx, const OrcMaterial* m, f3 d, const Hit* h, Paylo
         H = norm3(add3(L, V));
         float lightPdf = lightDst * lightDst / light->area / dot3(normalOnLight, neg3(L));
         float objPdf = disney_pdf(m, N, L, V, H);
+        if (g_disney_binary64) objPdf = (float)disney_pdf_d(m, Nd, dnorm(d_of(L)), dnorm(dadd(dnorm(d_of(L)), Vd)));
         if (lightPdf > 0 && objPdf > 0) {
           f3 brdf = disney_eval(m, baseColor, N, L, V, H);
+          if (g_disney_binary64) brdf = f_of(disney_eval_d(m, baseColor, Nd, dnorm(d_of(L)), Vd, dnorm(dadd(dnorm(d_of(L)), Vd))));
           f3 c = divs3(mul3(mul3(scl3(brdf, powerHeuristic(lightPdf, objPdf)), ld3(light->emission)), att), fmaxf(0.001f, lightPdf));
           direct = add3(direct, c);
         }
@@ -795,14 +899,21 @@ static void prog_disney(Ctx* cx, const OrcMaterial* m, f3 d, const Hit* h, Paylo
   }
 
   f3 indirect = mk3(0.f, 0.f, 0.f);
-  disney_sample(&p->randSeed, m, N, V, &L, &H);
+  d3 Ld = dmk(0, 0, 1), Hd = dmk(0, 0, 1);
+  if (g_disney_binary64) { disney_sample_d(&p->randSeed, m, Nd, Vd, &Ld, &Hd); L = f_of(Ld); H = f_of(Hd); }
+  else disney_sample(&p->randSeed, m, N, V, &L, &H);
   if (dot3(N, L) > 0.0f && dot3(N, V) > 0.0f) {
     Payload c = fork_payload(p);
     cx->st.bounceRays++;
     trace_radiance(cx, h->frontHitPoint, L, sc->rayEpsilonT, ORC_RT_DEFAULT_MAX, &c);
-    float pdf = disney_pdf(m, N, L, V, H);
+    float pdf = g_disney_binary64 ? (float)disney_pdf_d(m, Nd, Ld, Hd) : disney_pdf(m, N, L, V, H);
     if (pdf > 0) {
-      f3 brdf = disney_eval(m, baseColor, N, L, V, H);
+      f3 brdf = g_disney_binary64 ? mk3(0.f, 0.f, 0.f) : disney_eval(m, baseColor, N, L, V, H);
+      if (g_disney_binary64) {      /* brdf / pdf in binary64 as well */
+        const double pd = disney_pdf_d(m, Nd, Ld, Hd);
+        const d3 bd = disney_eval_d(m, baseColor, Nd, Ld, Vd, Hd);
+        indirect = mk3((float)(bd.x / pd * c.color.x), (float)(bd.y / pd * c.color.y), (float)(bd.z / pd * c.color.z));
+      } else
       indirect = divs3(mul3(brdf, c.color), pdf);
     }
   }

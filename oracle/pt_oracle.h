@@ -126,6 +126,8 @@ void orc_trace_one(const OrcScene* sc, const float org[3], const float dir[3],
 /* nearest-hit query used by BVH-vs-brute-force tests. returns prim id or -1 */
 int orc_closest_hit(const OrcScene* sc, const float org[3], const float dir[3],
                     float tmin, float tmax, float* tHit);
+/* "disney_binary64" = 1: evaluate disneySample/Pdf/Eval in binary64 (analysis only; see pt_oracle.c) */
+int orc_set_option(const char* name, int value);
 int orc_closest_hit_batch(const OrcScene* sc, const float* rays, int n, int32_t* outPrim, float* outT);
 
 /* ---- small pure functions exported for known-answer tests ---------------- */

@@ -225,3 +225,21 @@ def test_watchdog_reports_and_leaves_the_accumulator_alone(gpu_ctx):
     g, _ = _render(gpu_ctx, seeds[:2])
     o, _ = oracle_scene(small).render(seeds[:2])
     assert rmse(g / 2, o / 2) <= RMSE_TIGHT
+
+
+def test_coffee_with_glass_pot_standin(gpu_ctx):
+    """coffee.scene's Mesh010.obj (material Glass, brdf 1) is missing from the reference checkout; the lathe stand-in
+    puts a glass body in its place so that the benchmark scene's Disney GLASS branch (Material.cu:134-168) and the
+    shadow rays through glass (disneyAnyHit, Material.cu:226-227) run on the device."""
+    hs = M.HostScene("coffee_pot_standin", 320, 180)
+    assert hs.sizes.nFaces == 168193 + 8256
+    seeds = M.launch_seeds(3)
+    gpu_ctx.load(hs)
+    g, st = _render(gpu_ctx, seeds, counted=True)
+    o, ost = oracle_scene(hs).render(seeds)
+    assert rmse(g / 3, o / 3) <= RMSE_TIGHT
+    assert (st.primaryRays, st.bounceRays, st.shadowRays) == (ost.primaryRays, ost.bounceRays, ost.shadowRays)
+    plain = M.HostScene("file:coffee", 320, 180)
+    p, pst = oracle_scene(plain).render(seeds)
+    assert ost.bounceRays > pst.bounceRays * 1.05                     # paths bounce inside the glass
+    assert rmse(o / 3, p / 3) > 2e-2                                  # and the pot is visible

@@ -93,18 +93,74 @@ def test_oracle_reproduces_reference_demo_image(aperture, name):
     assert np.abs(blocks(img) - blocks(gold)).max() < 1.5e-2
 
 
-def test_oracle_coffee_matches_reference_demo_away_from_missing_pot():
-    """demo/coffee.png contains the glass pot (Mesh010.obj, missing from the reference checkout);
-    compare the regions that do not see it: the lit side walls/floor corners and the top of the machine."""
-    gold = np.load(os.path.join(GOLD, "coffee_8x.npy"))           # 135 x 240
-    hs = M.HostScene("file:coffee", 480, 270)
-    spp = 24
-    acc, _ = oracle_scene(hs).render(M.launch_seeds(spp))
-    img = O.image_from_accum(acc, spp).reshape(135, 2, 240, 2, 3).mean(axis=(1, 3))
-    regions = {"left light": (slice(20, 100), slice(0, 10)), "right light": (slice(20, 100), slice(232, 240)),
-               "machine top": (slice(8, 40), slice(100, 140)), "background": (slice(5, 60), slice(30, 80))}
-    for name, (ys, xs) in regions.items():
-        assert np.abs(img[ys, xs].mean(axis=(0, 1)) - gold[ys, xs].mean(axis=(0, 1))).max() < 3e-2, name
+# demo/coffee.png against the oracle, block by block.  One fixture block = 8x8 pixels of the 1920x1080 PNG; the oracle
+# renders the same footprint as one jittered pixel of a 240x135 frame (Camera.cu:28-29 box-filters the pixel), 1024 spp.
+# Regions are [y0:y1, x0:x1] in blocks, row 0 = top.  The glass pot (Mesh010.obj, absent from the checkout) and a
+# two-block margin around silhouettes (the PNG sits about one pixel to the left of the render) are left out.
+COFFEE_CLEAN = {          # what the reference image pins: (|signed mean| bound, mean |block diff| bound)
+    "back wall, left": ((10, 50, 20, 80), 1.5e-3, 5e-3),       # Disney diffuse lobe + NEE over three quad lights + MIS + clamp
+    "back wall, right": ((10, 50, 160, 190), 1.5e-3, 5e-3),
+    "machine body, centre": ((20, 60, 113, 128), 6e-3, 1.2e-2),   # Plastic_Orange away from the lights' reflections (seams inside)
+    "black base": ((70, 76, 105, 135), 3e-3, 1e-2),
+    "floor, middle left": ((95, 110, 30, 70), 5e-3, 1.2e-2),
+    "floor, bottom right": ((115, 133, 170, 215), 5e-3, 1.8e-2),
+}
+COFFEE_KNOWN = {          # where the PNG and the restated formulas differ, measured and kept visible (DESIGN.md "coffee.png pin")
+    # reflection of the side lights in Plastic_Orange (roughness 0.001): the PNG is ~1.22x brighter in G/B (R is saturated)
+    "light reflected in the body, left": ((20, 60, 101, 109), (-0.09, -0.02)),
+    "light reflected in the body, right": ((20, 60, 131, 139), (-0.09, -0.02)),
+    # floor in front of the machine: the PNG is brighter by 0.018, all channels alike
+    "floor, bottom left": ((115, 133, 20, 70), (-0.03, -0.008)),
+}
+
+
+def _coffee_region(sc, seeds, box):
+    y0, y1, x0, x1 = box
+    acc = np.zeros((135, 240, 3), np.float32)
+    sc.render(seeds, accum=acc, region=(x0, 135 - y1, x1, 135 - y0))       # accuBuffer rows run bottom-up
+    return O.image_from_accum(acc, len(seeds))[y0:y1, x0:x1]
+
+
+def test_oracle_coffee_matches_reference_demo_blockwise():
+    gold = np.load(os.path.join(GOLD, "coffee_8x.npy"))           # 135 x 240 blocks
+    sc = oracle_scene(M.HostScene("file:coffee", 240, 135))
+    seeds = M.launch_seeds(1024)
+    for name, (box, signed_tol, abs_tol) in COFFEE_CLEAN.items():
+        y0, y1, x0, x1 = box
+        d = _coffee_region(sc, seeds, box) - gold[y0:y1, x0:x1]
+        assert np.abs(d.mean(axis=(0, 1))).max() < signed_tol, (name, d.mean(axis=(0, 1)))
+        assert np.abs(d).mean() < abs_tol, (name, np.abs(d).mean())
+    for name, (box, (lo, hi)) in COFFEE_KNOWN.items():
+        y0, y1, x0, x1 = box
+        d = (_coffee_region(sc, seeds, box) - gold[y0:y1, x0:x1]).mean(axis=(0, 1))
+        assert lo < d[1] < hi and lo < d[2] < hi, (name, d)
+        if "body" in name:
+            assert abs(d[0]) < 6e-3, (name, d)                                        # red is saturated on both sides
+    # the two light panels themselves are saturated in both
+    for xs in (slice(0, 4), slice(236, 240)):
+        assert gold[20:100, xs].min() > 0.999
+
+
+def test_light_reflection_in_roughness_0001_plastic_depends_on_rounding():
+    """Plastic_Orange has roughness 0.001: GTR2's 1 + (a^2 - 1) cos^2 with a^2 = 1e-6 is formed from a cosine known to
+    6e-8, so the weight of a specular bounce depends on how each binary32 operation before it rounded.  Evaluating
+    the same formulas in binary64 (oracle analysis switch) moves the reflection of the side light by more than any
+    other region moves: part (about a quarter) of the gap to the PNG, which a -use_fast_math build cannot be
+    expected to hit, is rounding and not a missing BRDF term."""
+    gold = np.load(os.path.join(GOLD, "coffee_8x.npy"))
+    sc = oracle_scene(M.HostScene("file:coffee", 240, 135))
+    seeds = M.launch_seeds(512)
+    band, wall = (20, 60, 101, 109), (10, 50, 20, 50)
+    try:
+        f32 = {k: _coffee_region(sc, seeds, b).mean(axis=(0, 1)) for k, b in (("band", band), ("wall", wall))}
+        O.set_option("disney_binary64", 1)
+        f64 = {k: _coffee_region(sc, seeds, b).mean(axis=(0, 1)) for k, b in (("band", band), ("wall", wall))}
+    finally:
+        O.set_option("disney_binary64", 0)
+    assert f64["band"][2] - f32["band"][2] > 4e-3                 # blue = specular only (Cdlin.b = 7e-5)
+    assert np.abs(f64["wall"] - f32["wall"]).max() < 1e-3         # a rough surface does not care
+    y0, y1, x0, x1 = band
+    assert f64["band"][2] < gold[y0:y1, x0:x1, 2].mean()          # ... and binary64 does not reach the PNG either
 
 
 def test_oracle_bvh_equals_brute_force():
