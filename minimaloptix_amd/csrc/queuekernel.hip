@@ -50,22 +50,29 @@ constexpr int ring_capacity(int n) { int c = 1; while (c < n) c <<= 1; return c;
 // pool-wide queues first (they index PoolLds::queue); Q_NODE / Q_LEAF are per-wave rings (WavePriv)
 enum { Q_SHADE = 0, Q_GEN = 1, kNumQ = 2, Q_NODE = 2, Q_LEAF = 3, DEST_DONE = 4, DEST_NONE = -1 };
 
-struct alignas(16) SlotCold {           // 9 x 16 B, HBM, private to the pool
-  // path payload (shading / regeneration batches only)
-  int mode, pixel, item, depth;
-  uint32_t seed; float thrx, thry, thrz;
-  float radx, rady, radz; int mat;
-  float Nx, Ny, Nz; int light;
-  float Vx, Vy, Vz; float pendInv;
-  float pwx, pwy, pwz; float cdx;      // cd*: PathState::cdlin (textured materials), in the spare words of three rows
-  // "warm" ray state: needed by leaf passes and shading, not by the node loop
-  float dx, dy, dz, tmax;
-  int kind, bestTri, bestPrim; float cdy;
-  float c0, c1, c2; float cdz;         // beta, gamma | shadow attenuation
-};
-static_assert(sizeof(SlotCold) == 144, "SlotCold layout");
-
+// Path-slot record in HBM, private to the pool: eight 16-byte rows, grouped by WHO needs them and WHEN they change, so
+// that a visit moves only the rows it uses (round 1 moved all 144 bytes in and out on every shading visit and 48-80
+// bytes on every leaf visit: 474 B of scheduler state per ray, most of the kernel's fabric traffic):
+//   leaf pass                      reads dir (+ hit once a hit exists), writes hit only when the nearest hit changed
+//   shading, radiance ray back     reads ctl thr rad dir (+ hit)
+//   shading, shadow ray back       reads ctl thr rad nrm view pend (+ hit = attenuation, once a glass surface was crossed)
+//   new shadow ray                 writes ctl rad dir pend, and nrm view only for the first light of a Disney hit
+//   new radiance ray               writes ctl dir, and thr / rad only if they changed
+// What the rows do not hold lives in the slot's LDS flag word (ray type, "hit row valid"), or is implied: the pixel
+// follows from the work item, tmin is the scene's epsilon, a radiance ray's tmax is RT_DEFAULT_MAX and a shadow ray's
+// tmax is the tbest the node loop carries (a shadow ray never shortens it).
 struct alignas(16) i4 { int x, y, z, w; };
+struct alignas(16) SlotCold {
+  i4 ctl;     // item, depth, seed, mode | light << 3
+  v4 thr;     // throughput, cdlin.y
+  v4 rad;     // radiance so far, cdlin.z
+  v4 dir;     // d
+  v4 hit;     // radiance ray: bestTri, bestPrim (int bits), beta, gamma | shadow ray: attenuation
+  v4 nrm;     // Disney hit context while its lights are looped: N, mat (int bits)
+  v4 view;    // V, cdlin.x
+  v4 pend;    // weight of the shadow ray in flight: pendW, pendInv
+};
+static_assert(sizeof(SlotCold) == 128, "SlotCold layout");
 
 // Slot records stream through the cache hierarchy once per visit; PT_SLOT_NT marks their loads/stores
 // non-temporal so that they do not push BVH nodes out of the 4 MB L2 of the XCD.
@@ -121,7 +128,11 @@ typedef __attribute__((address_space(3))) int lds_int;
 // The LDS part is addressed through an address_space(3) pointer so that push/pop compile to
 // ds_write_b32/ds_read_b32 (a generic pointer makes the compiler merge the LDS and the HBM
 // overflow path into one flat_load).
-constexpr int kShadeFlag = 1 << 30;   // in stack[slot][0]: a finished ray goes to Q_SHADE (hit or shadow ray), not Q_GEN
+// flag bits next to the stack pointer in stack[slot][0]
+constexpr int kShadeFlag = 1 << 30;   // a finished ray goes to Q_SHADE (hit or shadow ray), not Q_GEN
+constexpr int kShadowRay = 1 << 29;   // the ray in flight is a shadow ray (MinimalOptiX.h:48 RAY_TYPE_SHADOW)
+constexpr int kHitValid = 1 << 28;    // SlotCold::hit holds this ray's nearest hit / attenuation (else: none yet / (1,1,1))
+constexpr int kSlotFlags = kShadeFlag | kShadowRay | kHitValid;
 
 struct SlotStack {
   lds_int* lds;           // &stack[slot][1]
@@ -222,9 +233,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
   {
     const int first = SHARED ? threadIdx.x : lane, step = SHARED ? kBlockThreads : 64;
     for (int s = first; s < NS; s += step) {
-      SlotCold c = {};
-      c.mode = M_NEW_PIXEL;
-      cold[s] = c;
+      i4 ctl; ctl.x = 0; ctl.y = 0; ctl.z = 0; ctl.w = M_NEW_PIXEL;
+      cold[s].ctl = ctl;
+      W.stack[s][0] = 0;
       W.queue[Q_GEN][s] = (unsigned short)s;
     }
     if constexpr (SHARED) {
@@ -250,7 +261,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
 
   // ---- node-loop worker context: the only per-lane state that survives between passes ----
   int ns = -1;                 // slot this lane is walking, -1 = none
-  int nsFlag = 0;              // kShadeFlag of that slot
+  int nsFlag = 0;              // flag bits (kSlotFlags) of that slot
   PathState nray;              // o, tmin used
   nray.o = mk3(0, 0, 0); nray.tmin = sc.epsT; nray.d = mk3(0, 0, 1); nray.tmax = 0; nray.kind = RK_RADIANCE; nray.mode = M_TRACE;
   Trav ntv;                    // inv, tbest, node, sp used
@@ -273,32 +284,42 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       PathState ps; Trav tv;
       ps.tmin = sc.epsT; ps.mode = M_TRACE;
       const v4 na = W.nodeA[slot], nb = W.nodeB[slot];
-      // the leaf is known from LDS: its triangles are requested together with the slot's warm rows (one round trip)
+      const int fl = W.stack[slot][0];
+      const bool shadow = (fl & kShadowRay) != 0, hitValid = (fl & kHitValid) != 0;
+      // the leaf is known from LDS: its triangles are requested together with the slot's rows (one round trip)
       LeafChunk ch;
       leaf_fetch4(sc, f2i(nb.w), 0, ch);
       const SlotCold* cs = cold + slot;
-      const v4 w0 = slot_load(reinterpret_cast<const v4*>(&cs->dx));
-      const i4 w1 = slot_load(reinterpret_cast<const i4*>(&cs->kind));
-      const v4 w2 = slot_load(reinterpret_cast<const v4*>(&cs->c0));
-      ps.o = mk3(na.x, na.y, na.z); ps.tmax = w0.w; ps.d = mk3(w0.x, w0.y, w0.z); ps.kind = w1.x;
+      const v4 wd = slot_load(&cs->dir);
+      v4 wh = mk4(0.f, 0.f, 0.f, 0.f);
+      if (hitValid) wh = slot_load(&cs->hit);
+      ps.o = mk3(na.x, na.y, na.z); ps.d = mk3(wd.x, wd.y, wd.z);
+      ps.kind = shadow ? RK_SHADOW : RK_RADIANCE;
+      ps.tmax = shadow ? na.w : kRtDefaultMax;
       tv.inv = mk3(nb.x, nb.y, nb.z); tv.tbest = na.w;
-      tv.node = f2i(nb.w); tv.sp = W.stack[slot][0] & ~kShadeFlag; tv.bestTri = w1.y; tv.bestPrim = w1.z;
-      tv.beta = w2.x; tv.gamma = w2.y; tv.att = mk3(w2.x, w2.y, w2.z);
+      tv.node = f2i(nb.w); tv.sp = fl & ~kSlotFlags;
+      tv.bestTri = -1; tv.bestPrim = -1; tv.beta = 0.f; tv.gamma = 0.f; tv.att = mk3(1.f, 1.f, 1.f);
+      if (hitValid) {
+        if (shadow) tv.att = mk3(wh.x, wh.y, wh.z);
+        else { tv.bestTri = f2i(wh.x); tv.bestPrim = f2i(wh.y); tv.beta = wh.z; tv.gamma = wh.w; }
+      }
+      const int oldTri = tv.bestTri, oldPrim = tv.bestPrim;
+      const v3 oldAtt = tv.att;
       SlotStack st = make_stack(slot);
       trav_leaf_step_fetched<CNT>(sc, ps, tv, st, ct, ch);
+      // most leaf visits find nothing nearer: the hit row is only written when it changed (beta / gamma change with bestTri)
+      const bool changed = shadow ? (tv.att.x != oldAtt.x || tv.att.y != oldAtt.y || tv.att.z != oldAtt.z)
+                                  : (tv.bestTri != oldTri || tv.bestPrim != oldPrim);
+      if (changed) {
+        v4 o2;
+        if (shadow) o2 = mk4(tv.att.x, tv.att.y, tv.att.z, 0.f);
+        else o2 = mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma);
+        slot_store(&cold[slot].hit, o2);
+      }
       W.nodeA[slot].w = tv.tbest;
       W.nodeB[slot].w = i2f(tv.node);
-      W.stack[slot][0] = tv.sp | ((ps.kind == RK_SHADOW || tv.bestPrim >= 0) ? kShadeFlag : 0);
-      i4 o1; o1.x = ps.kind; o1.y = tv.bestTri; o1.z = tv.bestPrim; o1.w = w1.w;
-      v4 o2;
-      if (ps.kind == RK_SHADOW) { o2.x = tv.att.x; o2.y = tv.att.y; o2.z = tv.att.z; } else { o2.x = tv.beta; o2.y = tv.gamma; o2.z = 0.f; }
-      o2.w = w2.w;
-      SlotCold* cw = cold + slot;
-      // most leaf visits find nothing nearer: only write the hit record back when it changed
-      if (o1.y != w1.y || o1.z != w1.z || o2.x != w2.x || o2.y != w2.y || o2.z != w2.z) {
-        slot_store(reinterpret_cast<i4*>(&cw->kind), o1);
-        slot_store(reinterpret_cast<v4*>(&cw->c0), o2);
-      }
+      W.stack[slot][0] = tv.sp | (fl & kShadowRay) | ((hitValid || changed) ? kHitValid : 0) |
+                         ((shadow || tv.bestPrim >= 0) ? kShadeFlag : 0);
       pendDest = route(tv.node, ps.kind, tv.bestPrim);
     }
     // Slot records in HBM are re-read by other lanes / waves.  With a shared pool a slot only reaches another wave
@@ -320,17 +341,33 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     // of the previous pass were left in flight, so they are ordered here, where their latency has already elapsed
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    bool shadowIn = false;                       // this visit started with a shadow ray coming back
+    v4 thrIn = mk4(0.f, 0.f, 0.f, 0.f), radIn = thrIn;
     if (have) {
-      const SlotCold c = slot_load(cold + slot);
+      const SlotCold* cs = cold + slot;
+      const int fl = W.stack[slot][0];
+      const bool shadow = (fl & kShadowRay) != 0, hitValid = (fl & kHitValid) != 0;
+      const i4 ctl = slot_load(&cs->ctl);
+      thrIn = slot_load(&cs->thr); radIn = slot_load(&cs->rad);
+      v4 wd = mk4(0.f, 0.f, 1.f, 0.f), wh = mk4(0.f, 0.f, 0.f, 0.f);
+      v4 wn = mk4(0.f, 0.f, 1.f, 0.f), wv = mk4(0.f, 0.f, 1.f, 0.f), wp = mk4(0.f, 0.f, 0.f, 0.f);
+      if (!shadow) wd = slot_load(&cs->dir);
+      if (hitValid) wh = slot_load(&cs->hit);
+      if (shadow) { wn = slot_load(&cs->nrm); wv = slot_load(&cs->view); wp = slot_load(&cs->pend); }
       const v4 na = W.nodeA[slot];
-      ps.mode = c.mode; ps.pixel = c.pixel; ps.item = c.item; ps.depth = c.depth; ps.seed = c.seed;
-      ps.thr = mk3(c.thrx, c.thry, c.thrz); ps.rad = mk3(c.radx, c.rady, c.radz); ps.mat = c.mat;
-      ps.N = mk3(c.Nx, c.Ny, c.Nz); ps.light = c.light; ps.V = mk3(c.Vx, c.Vy, c.Vz); ps.pendInv = c.pendInv;
-      ps.pendW = mk3(c.pwx, c.pwy, c.pwz); ps.accum = mk3(0, 0, 0); ps.cdlin = mk3(c.cdx, c.cdy, c.cdz);
-      ps.o = mk3(na.x, na.y, na.z); ps.tmax = c.tmax; ps.d = mk3(c.dx, c.dy, c.dz); ps.kind = c.kind; ps.tmin = sc.epsT;
-      res.tbest = na.w; res.bestTri = c.bestTri; res.bestPrim = c.bestPrim;
-      res.beta = c.c0; res.gamma = c.c1; res.att = mk3(c.c0, c.c1, c.c2);
-      if (ps.mode == M_TRACE) ps.mode = M_RESULT;
+      ps.mode = ctl.w & 7; ps.light = ctl.w >> 3; ps.item = ctl.x; ps.depth = ctl.y; ps.seed = (uint32_t)ctl.z; ps.pixel = 0;
+      ps.thr = mk3(thrIn.x, thrIn.y, thrIn.z); ps.rad = mk3(radIn.x, radIn.y, radIn.z);
+      ps.N = mk3(wn.x, wn.y, wn.z); ps.mat = f2i(wn.w); ps.V = mk3(wv.x, wv.y, wv.z);
+      ps.pendW = mk3(wp.x, wp.y, wp.z); ps.pendInv = wp.w; ps.accum = mk3(0, 0, 0);
+      ps.cdlin = mk3(wv.w, thrIn.w, radIn.w);
+      ps.o = mk3(na.x, na.y, na.z); ps.d = mk3(wd.x, wd.y, wd.z); ps.tmin = sc.epsT; ps.tmax = kRtDefaultMax;
+      ps.kind = shadow ? RK_SHADOW : RK_RADIANCE;
+      res.tbest = na.w; res.bestTri = -1; res.bestPrim = -1; res.beta = 0.f; res.gamma = 0.f; res.att = mk3(1.f, 1.f, 1.f);
+      if (hitValid) {
+        if (shadow) res.att = mk3(wh.x, wh.y, wh.z);
+        else { res.bestTri = f2i(wh.x); res.bestPrim = f2i(wh.y); res.beta = wh.z; res.gamma = wh.w; }
+      }
+      if (ps.mode == M_TRACE) { ps.mode = M_RESULT; shadowIn = shadow; }
     }
     if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBLoad); }
     for (;;) {
@@ -367,13 +404,15 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     }
     if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBRun); }
     if (have) {
-      SlotCold c;
-      c.mode = ps.mode; c.pixel = ps.pixel; c.item = ps.item; c.depth = ps.depth; c.seed = ps.seed;
-      c.thrx = ps.thr.x; c.thry = ps.thr.y; c.thrz = ps.thr.z; c.radx = ps.rad.x; c.rady = ps.rad.y; c.radz = ps.rad.z; c.mat = ps.mat;
-      c.Nx = ps.N.x; c.Ny = ps.N.y; c.Nz = ps.N.z; c.light = ps.light; c.Vx = ps.V.x; c.Vy = ps.V.y; c.Vz = ps.V.z; c.pendInv = ps.pendInv;
-      c.pwx = ps.pendW.x; c.pwy = ps.pendW.y; c.pwz = ps.pendW.z; c.cdx = ps.cdlin.x;
-      c.dx = ps.d.x; c.dy = ps.d.y; c.dz = ps.d.z; c.tmax = ps.tmax;
-      c.kind = ps.kind; c.bestTri = -1; c.bestPrim = -1; c.cdy = ps.cdlin.y; c.c0 = 0.f; c.c1 = 0.f; c.c2 = 0.f; c.cdz = ps.cdlin.z;
+      SlotCold* cw = cold + slot;
+      i4 ctl; ctl.x = ps.item; ctl.y = ps.depth; ctl.z = (int)ps.seed; ctl.w = ps.mode | (ps.light << 3);
+      slot_store(&cw->ctl, ctl);
+      // throughput and radiance rows: only when their bits changed (a shadow ray leaves thr alone, a glass bounce leaves rad alone)
+      const v4 thrOut = mk4(ps.thr.x, ps.thr.y, ps.thr.z, ps.cdlin.y), radOut = mk4(ps.rad.x, ps.rad.y, ps.rad.z, ps.cdlin.z);
+      if (f2i(thrOut.x) != f2i(thrIn.x) || f2i(thrOut.y) != f2i(thrIn.y) || f2i(thrOut.z) != f2i(thrIn.z) || f2i(thrOut.w) != f2i(thrIn.w))
+        slot_store(&cw->thr, thrOut);
+      if (f2i(radOut.x) != f2i(radIn.x) || f2i(radOut.y) != f2i(radIn.y) || f2i(radOut.z) != f2i(radIn.z) || f2i(radOut.w) != f2i(radIn.w))
+        slot_store(&cw->rad, radOut);
       if (ps.mode == M_TRACE) {
         // new ray: analytic primitives + traversal set-up happen here, on the full batch
         Trav tv;
@@ -382,13 +421,21 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         na.x = ps.o.x; na.y = ps.o.y; na.z = ps.o.z; na.w = tv.tbest;
         nb.x = tv.inv.x; nb.y = tv.inv.y; nb.z = tv.inv.z; nb.w = i2f(tv.node);
         W.nodeA[slot] = na; W.nodeB[slot] = nb;
-        W.stack[slot][0] = (ps.kind == RK_SHADOW || tv.bestPrim >= 0) ? kShadeFlag : 0;
-        c.bestTri = tv.bestTri; c.bestPrim = tv.bestPrim;
-        if (ps.kind == RK_SHADOW) { c.c0 = tv.att.x; c.c1 = tv.att.y; c.c2 = tv.att.z; }
-        slot_store(cold + slot, c);
+        const bool shadow = ps.kind == RK_SHADOW;
+        const bool hitNow = shadow ? (tv.att.x != 1.f || tv.att.y != 1.f || tv.att.z != 1.f) : (tv.bestPrim >= 0);
+        W.stack[slot][0] = ((shadow || tv.bestPrim >= 0) ? kShadeFlag : 0) | (shadow ? kShadowRay : 0) | (hitNow ? kHitValid : 0);
+        slot_store(&cw->dir, mk4(ps.d.x, ps.d.y, ps.d.z, 0.f));
+        if (hitNow) slot_store(&cw->hit, shadow ? mk4(tv.att.x, tv.att.y, tv.att.z, 0.f) : mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma));
+        if (shadow) {
+          slot_store(&cw->pend, mk4(ps.pendW.x, ps.pendW.y, ps.pendW.z, ps.pendInv));
+          if (!shadowIn) {      // first light of this Disney hit: N, V, material (and the texture colour) are new
+            slot_store(&cw->nrm, mk4(ps.N.x, ps.N.y, ps.N.z, i2f(ps.mat)));
+            slot_store(&cw->view, mk4(ps.V.x, ps.V.y, ps.V.z, ps.cdlin.x));
+          }
+        }
         pendDest = route(tv.node, ps.kind, tv.bestPrim);
       } else {
-        slot_store(cold + slot, c);
+        W.stack[slot][0] = 0;
         pendDest = (ps.mode == M_NEW_PIXEL) ? Q_GEN : DEST_DONE;
       }
     }
@@ -444,7 +491,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         int dest = DEST_NONE;
         if (leave) {
           W.nodeB[ns].w = i2f(ntv.node); W.stack[ns][0] = ntv.sp | nsFlag;
-          dest = (ntv.node == kTravDone) ? (nsFlag ? Q_SHADE : Q_GEN) : Q_LEAF;   // a lane leaves at a leaf or finished
+          dest = (ntv.node == kTravDone) ? ((nsFlag & kShadeFlag) ? Q_SHADE : Q_GEN) : Q_LEAF;   // a lane leaves at a leaf or finished
         }
         local_push(dest, ns);
         if (leave) ns = -1;
@@ -461,7 +508,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
             nray.o = mk3(na.x, na.y, na.z); ntv.tbest = na.w;
             ntv.inv = mk3(nb.x, nb.y, nb.z); ntv.node = f2i(nb.w);
             ntv.noi = neg_o_inv(nray.o, ntv.inv);
-            ntv.sp = spw & ~kShadeFlag; nsFlag = spw & kShadeFlag;
+            ntv.sp = spw & ~kSlotFlags; nsFlag = spw & kSlotFlags;
           }
         }
         nqHead = (nqHead + n) & (RC - 1); nqCount -= n;
