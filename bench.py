@@ -6,8 +6,10 @@
 
 A step = one frame of the metric's configuration: coffee.obj scene (168,193 triangles, LBVH),
 1920x1080, 256 spp = clear + 256 fused launches of the megakernel + ordered sample reduction
-(+ for N > 1 the RCCL gather of the tile-partitioned framebuffer to rank 0).  Scene, BVH and
-seeds are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+(+ for N > 1 one collective per frame: --split tile (default, north_star) gathers the tile-partitioned framebuffer
+to rank 0; --split sample gives rank r the launches i = r mod N over the whole frame and sums the accumulators with
+one reduce -- BASELINE.json configs[4]'s decomposition).  Scene, BVH and seeds are resident in HBM before the timed
+region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -21,6 +23,21 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
+# What actually serves the traversal's bytes: the 3.4 MB of nodes and 16 MB of triangle records are L2 / Infinity-Cache
+# resident.  Ceilings for independent random 64-byte gathers measured with tools/micro/gather.hip on MI355X.
+L2_GATHER_GBS = 13200.0     # 3.6 MB table (one XCD's L2 holds it)
+IC_GATHER_GBS = 4300.0      # 38 MB table (Infinity Cache)
+
+
+def source_hash(repo):
+    """Identifies the device code a profile belongs to: sha1 over minimaloptix_amd/csrc/* and the Makefile."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(repo, "minimaloptix_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../Makefile"]:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(st, pixels):
@@ -53,13 +70,17 @@ def cpu_baseline(width, height, target_s):
 
 
 def read_traffic(repo):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (collected separately, see
-    profiles/README.md); None when absent."""
+    """Counters of the trace kernel from the committed rocprofv3 PMC passes (collected separately: profiles/README.md,
+    tools/prof_bench.sh + tools/make_traffic_json.py).  Only used when they were collected on THIS device code
+    (source_hash); otherwise the fields are null rather than stale."""
     p = os.path.join(repo, "profiles", "traffic.json")
     try:
-        return json.load(open(p)).get("traffic_GB_per_launch")
+        t = json.load(open(p))
     except Exception:
         return None
+    if t.get("source_hash") != source_hash(repo):
+        return None
+    return t
 
 
 def main():
@@ -73,6 +94,7 @@ def main():
     ap.add_argument("--scene", default="file:coffee")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--split", choices=("tile", "sample"), default="tile", help="multi-GPU decomposition (N > 1)")
     a = ap.parse_args()
 
     import torch
@@ -107,13 +129,20 @@ def main():
     # rank's launch on a 1-GPU box; the JSON line then describes that share, not the frame
     emu = int(os.environ.get("MOPTIX_BENCH_EMULATE_RANKS", "0")) if world == 1 else 0
     part_rank, part_n = (0, emu) if emu > 1 else (rank, world)
-    ctx.set_partition(part_rank, part_n)
+    sample_split = a.split == "sample" and part_n > 1
+    if sample_split:
+        if a.spp % part_n:
+            raise SystemExit("--split sample needs spp divisible by the number of ranks")
+    else:
+        ctx.set_partition(part_rank, part_n)
     ctx.load(hs)
     info = ctx.accel_info()
     W, H = a.width, a.height
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
     ctx.accum_bind(accum.data_ptr())
     seeds = M.launch_seeds(a.spp)
+    if sample_split:
+        seeds = D.sample_split_seeds(seeds, part_rank, part_n)      # launches i = rank mod N (SURVEY 8d seed schedule)
     # Frame pipelining (N > 1): a rank's launch is short (frame / N), and the last ~20 ms of every launch are a drain in
     # which a few deep paths finish while most of the GPU idles.  Two contexts render alternate frames on their own
     # streams, so the next frame fills the CUs the draining one has released; every frame is still completed and
@@ -124,7 +153,8 @@ def main():
     ctxs, accums = [ctx], [accum]
     if pipeline:
         ctx2 = M.Context(local)
-        ctx2.set_partition(part_rank, part_n)
+        if not sample_split:
+            ctx2.set_partition(part_rank, part_n)
         ctx2.load(hs)
         accum2 = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
         ctx2.accum_bind(accum2.data_ptr())
@@ -138,15 +168,19 @@ def main():
     # counting launch (untimed): rays and algorithmic bytes of one frame are deterministic
     accum.zero_(); torch.cuda.synchronize()
     st = ctx.render_counted(seeds)
-    my_pixels = len(D.tile_pixel_indices(W, H, part_rank, part_n))
+    my_pixels = W * H if sample_split else len(D.tile_pixel_indices(W, H, part_rank, part_n))
     my_rays, my_bytes = st.rays, algorithmic_bytes(st, my_pixels)
     tot = torch.tensor([float(my_rays), float(my_bytes)], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tot)
     total_rays, total_bytes = float(tot[0].item()), float(tot[1].item())
 
-    def gather(j):
-        return D.gather_tiles(accums[j].view(H * W, 3), W, H, rank, world, dst=0) if world > 1 else None
+    def gather(j):                                                  # the frame's one collective
+        if world == 1:
+            return None
+        if sample_split:
+            return D.reduce_frame(accums[j], dst=0)
+        return D.gather_tiles(accums[j].view(H * W, 3), W, H, rank, world, dst=0)
 
     pending = [False] * len(ctxs)
     frame_no = [0]
@@ -193,14 +227,40 @@ def main():
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    kms, nlaunch = ctx.kernel_time()
-    reduce_ms = ctx.reduce_time()
+    kms, nlaunch, reduce_ms = 0.0, 0, 0.0
+    for c_ in ctxs:                                                 # both contexts when two frames are in flight
+        k_, n_ = c_.kernel_time()
+        kms += k_; nlaunch += n_; reduce_ms += c_.reduce_time()
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         launch_ms = kms / max(1, nlaunch)
         passes_per_step = max(1, nlaunch // max(1, a.steps))
         achieved = my_bytes / passes_per_step / (launch_ms * 1e-3) / 1e9          # GB/s, rank 0's trace kernel
+        if world == 1:
+            par = "single GPU" if emu <= 1 else "EMULATION: rank 0 of a %d-way %s split on one GPU" % (emu, a.split)
+        elif sample_split:
+            par = "sample-split x%d (rank r renders launches i = r mod %d) + RCCL reduce" % (world, world)
+        else:
+            par = "tile-split x%d (8x8 tiles dealt round-robin) + RCCL gather" % world
+        if pipeline:
+            par += ", two frames in flight"
+        traffic = read_traffic(REPO) if (world == 1 and emu <= 1 and a.scene == "file:coffee" and (W, H, a.spp) == (1920, 1080, 256)) else None
+        fabric_gb = traffic.get("traffic_GB_per_launch") if traffic else None
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": fabric_gb,
+                "kernel": "pt_queuekernel (trace)", "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
+                "algorithmic_bytes_per_launch": int(my_bytes // passes_per_step),
+                "bytes_per_ray": round(my_bytes / max(1, my_rays), 1), "reduce_ms_total": round(reduce_ms, 3),
+                # `achieved` counts ALGORITHMIC bytes and most of them never leave L2 / Infinity Cache: it is the
+                # agreed figure of merit, not HBM bandwidth.  What the memory system really did, from the PMC passes:
+                "served_from": "L2 / Infinity Cache (19 MB working set); see fabric_* for what crossed the fabric",
+                "fabric_GBps": round(fabric_gb / (launch_ms * 1e-3), 1) if fabric_gb else None,
+                "fabric_frac_of_hbm_peak": round(fabric_gb / (launch_ms * 1e-3) / HBM_PEAK_GBS, 4) if fabric_gb else None,
+                "tcc_hit_rate": traffic.get("tcc_hit_rate") if traffic else None,
+                "fabric_bytes_per_ray": round(fabric_gb * 1e9 / max(1, my_rays), 1) if fabric_gb else None,
+                "l2_gather_ceiling_GBps": L2_GATHER_GBS, "frac_of_l2_gather_ceiling": round(achieved / L2_GATHER_GBS, 4),
+                "infinity_cache_gather_ceiling_GBps": IC_GATHER_GBS}
         out = {
             "metric": "Mrays/s (primary+bounce+shadow rays traced per second, coffee.obj 1920x1080 256spp)",
             "value": round(total_rays / (dt / a.steps) / 1e6, 2), "unit": "Mrays/s",
@@ -209,15 +269,11 @@ def main():
             "data": "reference scene scenes/coffee (168,193 triangles; Mesh010 missing upstream), synthetic seed schedule tea16(i,0)",
             "config": {"workload": "coffee.obj LBVH build+traverse, %dx%d, %d spp (BASELINE.json configs[2])" % (W, H, a.spp),
                        "scene": a.scene, "width": W, "height": H, "spp": a.spp, "rays_per_frame": int(total_rays),
-                       "parallelism": ("tile-split x%d + RCCL gather, two frames in flight" % world) if world > 1 else
-                                      ("single GPU" if emu <= 1 else "EMULATION: rank 0 of a %d-way tile split on one GPU" % emu),
+                       "parallelism": par, "split": a.split if world > 1 else None, "pipeline": bool(pipeline),
                        "kernel_variant": ctx.get_option("kernel_variant"), "bvh_nodes": int(info.nNodes), "bvh_depth": int(info.treeDepth),
-                       "bvh_build_ms": round(float(info.buildMs), 3), "ms_per_frame": round(ms_per_step, 3)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": read_traffic(REPO),
-                         "kernel": "pt_queuekernel (trace)", "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
-                         "algorithmic_bytes_per_launch": int(my_bytes // passes_per_step),
-                         "bytes_per_ray": round(my_bytes / max(1, my_rays), 1), "reduce_ms_total": round(reduce_ms, 3)},
+                       "bvh_build_ms": round(float(info.buildMs), 3), "ms_per_frame": round(ms_per_step, 3),
+                       "source_hash": source_hash(REPO)},
+            "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(W, H, a.cpu_seconds)

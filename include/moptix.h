@@ -189,7 +189,11 @@ int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
  *   "blocks_per_cu"    resident workgroups per CU (default 3)
  *   "swap_lanes", "starve_lanes"   node-loop swap / starvation thresholds of variants 2 and 3
  *   "exit_threshold" (variant 0), "pool_slots" (128|192|256), "refill_lanes", "leaf_threshold" (variant 1)
- *   "sample_buffer_mb" budget of the per-sample buffer; larger batches run in passes
+ *   "sample_buffer_mb" budget of the per-sample buffer (default 16384); larger batches run in passes
+ *   "fast_shading"     0 (default): disneyPdf / disneyEval in correctly rounded binary32, bit-parity with the oracle;
+ *                      1: hardware reciprocal / square-root approximations there (the reference itself is built with
+ *                      -use_fast_math, utils_host.cpp:30-32): same rays, BRDF weights within ~1e-6, default kernel only
+ *   "watchdog_ms"      wall-clock bound of one render kernel (default 600000); a pass cut short is not accumulated
  * Unknown names -> MOPTIX_ERR_INVALID. */
 int moptix_set_option(moptix_context ctx, const char* name, int32_t value);
 int moptix_get_option(moptix_context ctx, const char* name, int32_t* value);

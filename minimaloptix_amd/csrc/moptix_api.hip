@@ -75,11 +75,12 @@ struct moptix_context_t {
   int optTileMajor = 1;
   long long tileHistoryTiles = -1;
   DevBuf<unsigned int> dTileCost, dTileCostSorted; DevBuf<int> dTileOrder, dTileIota; DevBuf<uint8_t> dSortTmp;
-  int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 8192, optLeafThreshold = 16, optSwapLanes = 32;
+  int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 16384, optLeafThreshold = 16, optSwapLanes = 32;
   unsigned long long lastExtra[5] = { 0, 0, 0, 0, 0 };
 
   std::vector<int> seedStaging;
   int optWatchdogMs = 600000;
+  int optFastShading = 0;
   double kernelMs = 0.0, reduceMs = 0.0; uint64_t nLaunches = 0;
   bool asyncPending = false;
 };
@@ -264,7 +265,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
                                                (size_t)historyUnits, 0, 32, c->stream), "sort tiles");
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
-    if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, c->optVariant == 3, counted), "launch queue megakernel");
+    if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, c->optVariant == 3, counted, c->optFastShading != 0), "launch queue megakernel");
     else if (usePool) HIPCHK(c, launch_poolkernel(c->stream, a, nBlocks, c->optPoolSlots, counted), "launch pool megakernel");
     else HIPCHK(c, launch_megakernel(c->stream, a, nBlocks, counted), "launch megakernel");
     HIPCHK(c, hipEventRecord(c->ev1, c->stream), "event");
@@ -577,6 +578,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "refill_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "refill_lanes in [1,64]"); c->optRefillLanes = value; }
   else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
   else if (!strcmp(name, "tile_major")) { if (value < 0 || value > 3) return fail(c, MOPTIX_ERR_INVALID, "tile_major in {0,1,2,3}"); c->optTileMajor = value; }
+  else if (!strcmp(name, "fast_shading")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "fast_shading in {0,1}"); c->optFastShading = value; }
   else if (!strcmp(name, "watchdog_ms")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "watchdog_ms >= 1"); c->optWatchdogMs = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
@@ -596,6 +598,7 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "starve_lanes")) *value = c->optStarveLanes;
   else if (!strcmp(name, "tile_major")) *value = c->optTileMajor;
   else if (!strcmp(name, "watchdog_ms")) *value = c->optWatchdogMs;
+  else if (!strcmp(name, "fast_shading")) *value = c->optFastShading;
   else if (!strcmp(name, "num_cus")) *value = c->numCUs;
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;

@@ -6,6 +6,26 @@
 
 namespace pt {
 
+// Arithmetic of the three Disney functions.  FAST = false (default, and the only mode the parity contract knows):
+// correctly rounded binary32 division and square root, as the oracle evaluates them.  FAST = true (opt-in,
+// moptix_set_option("fast_shading", 1); device only): the hardware approximations v_rcp_f32 / v_sqrt_f32 / v_rsq_f32
+// (1 ulp), which is what the reference's own -use_fast_math build does (utils_host.cpp:30-32).  Only disney_pdf and
+// disney_eval use it -- pure weights.  Intersection, hit-point refinement, RNG, light sampling and the sampled bounce
+// direction (disney_sample) stay exact, so the same rays are traced and only BRDF / pdf values move (by ~1e-6 relative).
+template <bool FAST> struct ShadeMath {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static PT_HD float rcp(float x) { if constexpr (FAST) return __builtin_amdgcn_rcpf(x); else return 1.0f / x; }
+  static PT_HD float div(float a, float b) { if constexpr (FAST) return a * __builtin_amdgcn_rcpf(b); else return a / b; }
+  static PT_HD float sqrt(float x) { if constexpr (FAST) return __builtin_amdgcn_sqrtf(x); else return __builtin_sqrtf(x); }
+  static PT_HD v3 normalize(v3 a) { if constexpr (FAST) return a * __builtin_amdgcn_rsqf(dot(a, a)); else return pt::normalize(a); }
+#else                                   // host pass of hipcc / tests/hostsim: exact arithmetic whatever FAST says
+  static PT_HD float rcp(float x) { return 1.0f / x; }
+  static PT_HD float div(float a, float b) { return a / b; }
+  static PT_HD float sqrt(float x) { return __builtin_sqrtf(x); }
+  static PT_HD v3 normalize(v3 a) { return pt::normalize(a); }
+#endif
+};
+
 // utils_device.h:63-67
 PT_HD float fresnel(float cosThetaI, float cosThetaT, float refIdx) {
   float rs = (cosThetaI - cosThetaT * refIdx) / (cosThetaI + refIdx * cosThetaT);
@@ -13,20 +33,24 @@ PT_HD float fresnel(float cosThetaI, float cosThetaT, float refIdx) {
   return 0.5f * (rs * rs + rp * rp);
 }
 // utils_device.h:130-137 with a = ccAlpha of the material (the only `a` it is called with)
+template <bool FAST = false>
 PT_HD float GTR1_cc(float NDotH, const DevMaterial& m) {
   if (m.ccAlpha >= 1.f) return 1.f / kPi;
   float t = 1.f + m.ccA2m1 * NDotH * NDotH;
-  return m.ccA2m1 / (m.ccPiLogA2 * t);
+  return ShadeMath<FAST>::div(m.ccA2m1, m.ccPiLogA2 * t);
 }
 // utils_device.h:139-143
+template <bool FAST = false>
 PT_HD float GTR2(float NDotH, float a) {
   float a2 = a * a;
   float t = 1.f + (a2 - 1.f) * NDotH * NDotH;
-  return a2 / (kPi * t * t);
+  return ShadeMath<FAST>::div(a2, kPi * t * t);
 }
 // utils_device.h:149-151
+template <bool FAST = false>
 PT_HD float GTR2Aniso(float NdotH, float HdotX, float HdotY, float ax, float ay) {
-  return 1 / (kPi * ax * ay * sqr(sqr(HdotX / ax) + sqr(HdotY / ay) + NdotH * NdotH));
+  typedef ShadeMath<FAST> SM;
+  return SM::rcp(kPi * ax * ay * sqr(sqr(SM::div(HdotX, ax)) + sqr(SM::div(HdotY, ay)) + NdotH * NdotH));
 }
 // utils_device.h:153-157
 PT_HD float schlickFresnel(float u) {
@@ -35,14 +59,16 @@ PT_HD float schlickFresnel(float u) {
   return m2 * m2 * m;
 }
 // utils_device.h:159-163
+template <bool FAST = false>
 PT_HD float smithGGgx(float NdotV, float alphaG) {
   float a = alphaG * alphaG;
   float b = NdotV * NdotV;
-  return 1.f / (NdotV + __builtin_sqrtf(a + b - a * b));
+  return ShadeMath<FAST>::rcp(NdotV + ShadeMath<FAST>::sqrt(a + b - a * b));
 }
 // utils_device.h:165-167
+template <bool FAST = false>
 PT_HD float smithGGgxAniso(float NdotV, float VdotX, float VdotY, float ax, float ay) {
-  return 1.0f / (NdotV + __builtin_sqrtf(sqr(VdotX * ax) + sqr(VdotY * ay) + sqr(NdotV)));
+  return ShadeMath<FAST>::rcp(NdotV + ShadeMath<FAST>::sqrt(sqr(VdotX * ax) + sqr(VdotY * ay) + sqr(NdotV)));
 }
 // utils_device.h:182-185
 PT_HD float powerHeuristic(float a, float b) { float t = a * a; return t / (b * b + t); }
@@ -62,43 +88,48 @@ PT_HD v3 cosine_sample_hemisphere(float u1, float u2) {
 
 // disney.h:9-30
 PT_HD_BRDF void disney_sample(uint32_t& seed, const DevMaterial& m, v3 N, v3 V, v3& L, v3& H) {
+  typedef ShadeMath<false> SM;         // directions are part of the path: always exact
   Onb onb = make_onb(N);
   if (rnd(seed) < m.diffuseRatio) {
     float u1 = rnd(seed); float u2 = rnd(seed);
     v3 l = cosine_sample_hemisphere(u1, u2);
     l = onb_inverse(onb, l);
-    L = normalize(l);
-    H = normalize(L + V);
+    L = SM::normalize(l);
+    H = SM::normalize(L + V);
   } else {
     float a = m.specAlpha;
     float phi = rnd(seed) * 2.0f * kPi;
     float random = rnd(seed);
-    float cosTheta = __builtin_sqrtf((1.f - random) / (1.0f + (a * a - 1.f) * random));
-    float sinTheta = __builtin_sqrtf(1.0f - (cosTheta * cosTheta));
+    float cosTheta = SM::sqrt(SM::div(1.f - random, 1.0f + (a * a - 1.f) * random));
+    float sinTheta = SM::sqrt(1.0f - (cosTheta * cosTheta));
     float sinPhi, cosPhi;
     sincos_ac(phi, sinPhi, cosPhi);
     v3 h = mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
     h = onb_inverse(onb, h);
-    L = normalize(h * (2.0f * dot(V, h)) - V);
-    H = normalize(h);
+    L = SM::normalize(h * (2.0f * dot(V, h)) - V);
+    H = SM::normalize(h);
   }
 }
 
 // disney.h:32-46
+template <bool FAST = false>
 PT_HD_BRDF float disney_pdf(const DevMaterial& m, v3 N, v3 L, v3 H) {
+  typedef ShadeMath<FAST> SM;
   float specularRatio = 1.f - m.diffuseRatio;
   float cosTheta = __builtin_fabsf(dot(N, H));
-  float pdfGTR1 = GTR1_cc(cosTheta, m) * cosTheta;
-  float pdfGTR2 = GTR2(cosTheta, m.specAlpha) * cosTheta;
+  float pdfGTR1 = GTR1_cc<FAST>(cosTheta, m) * cosTheta;
+  float pdfGTR2 = GTR2<FAST>(cosTheta, m.specAlpha) * cosTheta;
   float pdfH = lerp(pdfGTR1, pdfGTR2, m.ccRatio);
-  float pdfL = pdfH / (4.0f * __builtin_fabsf(dot(L, H)));
-  float pdfDiff = __builtin_fabsf(dot(N, L)) / kPi;
+  float pdfL = SM::div(pdfH, 4.0f * __builtin_fabsf(dot(L, H)));
+  float pdfDiff = SM::div(__builtin_fabsf(dot(N, L)), kPi);
   return m.diffuseRatio * pdfDiff + specularRatio * pdfL;
 }
 
 // disney.h:48-91
 // Cdlin/Cspec0/Csheen: the material's constants, or the per-hit ones of a textured material
+template <bool FAST = false>
 PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 Cdlin, v3 Cspec0, v3 Csheen, v3 N, v3 L, v3 V, v3 H) {
+  typedef ShadeMath<FAST> SM;
   Onb onb = make_onb(N);
   float NdotL = dot(N, L), NdotV = dot(N, V), NdotH = dot(N, H), LdotH = dot(L, H);
   const v3 one = mk3(1.f, 1.f, 1.f);
@@ -110,19 +141,19 @@ PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 Cdlin, v3 Cspec0, v3 Csheen, 
 
   float Fss90 = LdotH * LdotH * m.roughness;
   float Fss = lerp(1.0f, Fss90, FL) * lerp(1.0f, Fss90, FV);
-  float ss = 1.25f * (Fss * (1.f / (NdotL + NdotV) - 0.5f) + 0.5f);
+  float ss = 1.25f * (Fss * (SM::rcp(NdotL + NdotV) - 0.5f) + 0.5f);
 
-  v3 X = normalize(onb.tangent);
-  v3 Y = normalize(cross(N, X));
-  float Ds = GTR2Aniso(NdotH, dot(H, X), dot(H, Y), m.ax, m.ay);
+  v3 X = SM::normalize(onb.tangent);
+  v3 Y = SM::normalize(cross(N, X));
+  float Ds = GTR2Aniso<FAST>(NdotH, dot(H, X), dot(H, Y), m.ax, m.ay);
   float FH = schlickFresnel(LdotH);
   v3 Fs = lerp(Cspec0, one, FH);
-  float Gs = smithGGgxAniso(NdotL, dot(L, X), dot(L, Y), m.ax, m.ay) *
-             smithGGgxAniso(NdotV, dot(V, X), dot(V, Y), m.ax, m.ay);
+  float Gs = smithGGgxAniso<FAST>(NdotL, dot(L, X), dot(L, Y), m.ax, m.ay) *
+             smithGGgxAniso<FAST>(NdotV, dot(V, X), dot(V, Y), m.ax, m.ay);
   v3 Fsheen = Csheen * (FH * m.sheen);
-  float Dr = GTR1_cc(NdotH, m);
+  float Dr = GTR1_cc<FAST>(NdotH, m);
   float Fr = lerp(0.04f, 1.f, FH);
-  float Gr = smithGGgx(NdotL, 0.25f) * smithGGgx(NdotV, 0.25f);
+  float Gr = smithGGgx<FAST>(NdotL, 0.25f) * smithGGgx<FAST>(NdotV, 0.25f);
   v3 diffuse = (Cdlin * ((1.0f / kPi) * lerp(Fd, ss, m.subsurface)) + Fsheen) * m.oneMinusMetallic;
   v3 spec = (Fs * Gs) * Ds;
   float cc = 0.25f * m.clearcoat * Gr * Fr * Dr;

@@ -431,7 +431,7 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
 // direction per lane; disney_pdf/disney_eval -- the expensive part -- are then evaluated once,
 // for light candidates and bounce candidates together, so a shading batch runs them on a full
 // wave.  Same formulas and the same RNG draw order as the reference's program.
-template <bool CNT>
+template <bool CNT, bool FAST = false>
 PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
   const DevMaterial& m = sc.mats[ps.mat];
   int choice = 0;                       // 0 nothing, 1 shadow ray towards a light, 2 BRDF bounce
@@ -472,8 +472,8 @@ PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
     Cdlin = ps.cdlin;
     disney_color_constants(Cdlin, m.specular, m.specularTint, m.sheenTint, m.metallic, Cspec0, Csheen);
   }
-  const float pdf = disney_pdf(m, ps.N, L, H);
-  const v3 brdf = disney_eval(m, Cdlin, Cspec0, Csheen, ps.N, L, ps.V, H);
+  const float pdf = disney_pdf<FAST>(m, ps.N, L, H);
+  const v3 brdf = disney_eval<FAST>(m, Cdlin, Cspec0, Csheen, ps.N, L, ps.V, H);
 
   if (choice == 1) {
     if (lightPdf > 0 && pdf > 0) {

@@ -162,7 +162,7 @@ __device__ __forceinline__ int route(int node, int kind, int bestPrim) {
   return node >= 0 ? Q_NODE : Q_LEAF;
 }
 
-template <bool CNT, bool SHARED>
+template <bool CNT, bool SHARED, bool FAST = false>
 __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(const LaunchArgs a) {
   constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
   constexpr int RC = ring_capacity(NS);                  // ring capacity (power of two >= NS)
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         if (ps.mode == M_RESULT) {
           on_result<CNT>(sc, ps, res, ct);
         } else if (ps.mode == M_LIGHTS) {
-          on_lights<CNT>(sc, ps, ct);
+          on_lights<CNT, FAST>(sc, ps, ct);
         } else {  // M_NEW_PIXEL: next (pixel, sample) work item
           int k = atomicAdd(a.workCounter, 1);
           k = (k >= a.nWork) ? -1 : handout_to_item(a, k);
@@ -609,9 +609,12 @@ int queuekernel_slots() { return kP; }
 size_t queuekernel_cold_bytes(int nBlocks) { return (size_t)nBlocks * kWaves * kP * sizeof(SlotCold); }
 size_t queuekernel_overflow_ints(int nBlocks, int ovfDepth) { return (size_t)nBlocks * kWaves * kP * (size_t)ovfDepth; }
 
-hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool shared, bool counted) {
+hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool shared, bool counted, bool fastShading) {
   dim3 grid(nBlocks), block(kBlockThreads);
-  if (shared) {
+  if (shared && fastShading) {       // opt-in approximate BRDF arithmetic (pt_disney.h ShadeMath); default variant only
+    if (counted) pt_queuekernel<true, true, true><<<grid, block, 0, stream>>>(a);
+    else         pt_queuekernel<false, true, true><<<grid, block, 0, stream>>>(a);
+  } else if (shared) {
     if (counted) pt_queuekernel<true, true><<<grid, block, 0, stream>>>(a);
     else         pt_queuekernel<false, true><<<grid, block, 0, stream>>>(a);
   } else {

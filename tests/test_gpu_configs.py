@@ -243,3 +243,28 @@ def test_coffee_with_glass_pot_standin(gpu_ctx):
     p, pst = oracle_scene(plain).render(seeds)
     assert ost.bounceRays > pst.bounceRays * 1.05                     # paths bounce inside the glass
     assert rmse(o / 3, p / 3) > 2e-2                                  # and the pot is visible
+
+
+def test_fast_shading_mode_keeps_the_paths_and_moves_weights_by_1e_6(gpu_ctx):
+    """Opt-in "fast_shading": v_rcp / v_sqrt / v_rsq inside disneyPdf / disneyEval only (the reference is a
+    -use_fast_math build, utils_host.cpp:30-32).  Same rays as the exact mode (every counter equal), RMSE against the
+    oracle far inside north_star's 1e-3 at the benchmark's frame size and sample count, and not bit-identical."""
+    W, H, spp = 1920, 1080, 256
+    hs = M.HostScene("file:coffee", W, H)
+    seeds = M.launch_seeds(spp)
+    gpu_ctx.load(hs)
+    exact, st0 = _render(gpu_ctx, seeds[:8], counted=True)
+    try:
+        gpu_ctx.set_option("fast_shading", 1)
+        fast8, st1 = _render(gpu_ctx, seeds[:8], counted=True)
+        fast, _ = _render(gpu_ctx, seeds)
+    finally:
+        gpu_ctx.set_option("fast_shading", 0)
+    for f in ("primaryRays", "bounceRays", "shadowRays", "closestHits", "nodeFetches", "triTests"):
+        assert getattr(st0, f) == getattr(st1, f), f
+    assert not np.array_equal(exact, fast8)
+    assert rmse(exact / 8, fast8 / 8) < 1e-5
+    y0, y1 = 500, 516
+    o, _ = oracle_scene(hs).render(seeds, region=(0, y0, W, y1), threads=THREADS)
+    e = rmse(fast[y0:y1] / spp, o[y0:y1] / spp)
+    assert e <= 1e-3 and e <= 1e-5, e

@@ -1,0 +1,46 @@
+"""profiles/traffic.json from the separate rocprofv3 --pmc passes of tools/prof_bench.sh.
+
+  python3 tools/make_traffic_json.py gpurun_out/prof_bench_<tag> [profiles/traffic.json]
+
+Per-launch counters of the trace kernel (pt_queuekernel<false,true>): FETCH_SIZE and WRITE_SIZE (KB; FETCH_SIZE =
+TCC_EA0_RDREQ x 64 B -- the guide's x2 correction is for wide coalesced streams and is NOT applied to these 16-byte
+gathers), TCC_HIT / TCC_MISS.  The file is stamped with bench.source_hash(): bench.py ignores it for any other
+device code."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench   # noqa: E402
+
+src = sys.argv[1]
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "profiles", "traffic.json")
+agg, cnt = collections.defaultdict(float), collections.Counter()
+for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name", "")
+        if "pt_queuekernel<false" not in name:
+            continue
+        k = r.get("Counter_Name")
+        agg[k] += float(r.get("Counter_Value", 0)); cnt[k] += 1
+per = {k: agg[k] / cnt[k] for k in agg}
+need = ("FETCH_SIZE", "WRITE_SIZE")
+if any(k not in per for k in need):
+    raise SystemExit("missing counters: have %s" % sorted(per))
+out = {
+    "source": "%s (separate --pmc passes of `python3 bench.py --steps 1 --warmup 0`)" % src,
+    "source_hash": bench.source_hash(REPO),
+    "kernel": "pt_queuekernel<false,true>",
+    "FETCH_SIZE_KB_per_launch": per["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": per["WRITE_SIZE"],
+    "traffic_GB_per_launch": round((per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024 / 1e9, 1),
+    "TCC_HIT_per_launch": per.get("TCC_HIT_sum"), "TCC_MISS_per_launch": per.get("TCC_MISS_sum"),
+    "tcc_hit_rate": round(per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in per else None,
+    "SQ": {k: per[k] for k in sorted(per) if k.startswith("SQ_")},
+    "note": "raw counters x 1024 B; uncalibrated for 16 B/lane gathers (guide: HBM section), compare between builds of this kernel",
+}
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1))

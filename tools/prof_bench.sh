@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the bench.py command (run on the GPU box via gpurun):
 #   kernel-trace --stats of `python3 bench.py` and separate PMC passes for HBM traffic.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_bench_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -26,3 +26,4 @@ for d in sorted(glob.glob("$OUT/*/")):
             agg[k] += float(r.get("Counter_Value", 0)); cnt[k] += 1
         for k in sorted(agg): print("   %-48s %-24s sum=%.6g launches=%d per_launch=%.6g" % (k[0], k[1], agg[k], cnt[k], agg[k] / cnt[k]))
 PY
+python3 tools/make_traffic_json.py $OUT $OUT/traffic.json
