@@ -16,8 +16,9 @@ struct LbvhResult {
 
 // facePos: 9 floats per face (p0 p1 p2) in upload order; faceNrm: 9 per face; device pointers.
 // Allocates the result arrays with hipMalloc (caller frees with lbvh_free).
+// builder: 0 = Morton radix tree (Karras 2012), 1 = binned-SAH topology over the Morton order (pt_lbvh.h)
 hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dFaceNrm, const int* dFaceHasNrm,
-                      const int* dFaceMat, int nFaces, int leafSize, LbvhResult* out);
+                      const int* dFaceMat, int nFaces, int leafSize, int builder, LbvhResult* out);
 void lbvh_free(LbvhResult* r);
 
 }  // namespace pt

@@ -106,6 +106,124 @@ __global__ void k_karras(int n, const uint64_t* __restrict__ keys, int* __restri
   if (i == 0) parentI[0] = -1;
 }
 
+// 4'. binned-SAH topology (pt_lbvh.h), one workgroup per node of the current level
+struct SahTask { int node, first, count; float cbLo[3], cbHi[3]; };
+
+__global__ void k_sah_init(int n, const uint64_t* __restrict__ keys, int* __restrict__ order, SahTask* task0, const SceneBox* box) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) order[k] = key_face(keys[k], lbvh_index_bits(n));
+  if (k == 0) {
+    SahTask t; t.node = 0; t.first = 0; t.count = n;
+    for (int a = 0; a < 3; a++) { t.cbLo[a] = ordered_to_float(box->cLo[a]); t.cbHi[a] = ordered_to_float(box->cHi[a]); }
+    *task0 = t;
+  }
+}
+
+constexpr int kSahBlock = 256;
+__global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restrict__ tasks, int leafSize, int useSah,
+                                                         const float* __restrict__ lo, const float* __restrict__ hi,
+                                                         int* order, int* tmp, int* __restrict__ first, int* __restrict__ last,
+                                                         SahTask* __restrict__ children) {
+  __shared__ SahBins B;
+  __shared__ SahSplit sSplit;
+  __shared__ uint32_t sCb[2][2][3];          // [side][lo|hi][axis], order-preserving uints
+  __shared__ int sWave[2][kSahBlock / 64];
+  __shared__ int sBase[2];
+  const SahTask t = tasks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float base[3] = { t.cbLo[0], t.cbLo[1], t.cbLo[2] };
+  const float scale[3] = { sah_scale(t.cbLo[0], t.cbHi[0]), sah_scale(t.cbLo[1], t.cbHi[1]), sah_scale(t.cbLo[2], t.cbHi[2]) };
+  const bool binned = useSah && t.count > leafSize;
+  if (binned) {
+    for (int i = tid; i < 3 * kSahBins; i += kSahBlock) {
+      const int a = i / kSahBins, b = i % kSahBins;
+      B.cnt[a][b] = 0;
+      for (int k = 0; k < 3; k++) { B.lo[a][b][k] = float_to_ordered(1e37f); B.hi[a][b][k] = float_to_ordered(-1e37f); }
+    }
+  }
+  if (tid < 12) sCb[tid / 6][(tid / 3) & 1][tid % 3] = float_to_ordered(((tid / 3) & 1) ? -1e37f : 1e37f);
+  if (tid == 0) { sBase[0] = 0; sBase[1] = 0; sSplit.axis = -1; sSplit.bin = 0; sSplit.nLeft = (t.count + 1) / 2; }
+  __syncthreads();
+  if (binned) {
+    for (int i = tid; i < t.count; i += kSahBlock) {
+      const int f = order[t.first + i];
+      const float l[3] = { lo[3 * f], lo[3 * f + 1], lo[3 * f + 2] }, h[3] = { hi[3 * f], hi[3 * f + 1], hi[3 * f + 2] };
+      for (int a = 0; a < 3; a++) {
+        const int b = sah_bin((l[a] + h[a]) * 0.5f, base[a], scale[a]);
+        atomicAdd(&B.cnt[a][b], 1);
+        for (int k = 0; k < 3; k++) { atomicMin(&B.lo[a][b][k], float_to_ordered(l[k])); atomicMax(&B.hi[a][b][k], float_to_ordered(h[k])); }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) sSplit = sah_choose(B, mk3(t.cbLo[0], t.cbLo[1], t.cbLo[2]), mk3(t.cbHi[0], t.cbHi[1], t.cbHi[2]), t.count);
+    __syncthreads();
+  }
+  const SahSplit sp = sSplit;
+  // stable partition of the range into tmp, centroid boxes of the halves on the way
+  for (int b0 = 0; b0 < t.count; b0 += kSahBlock) {
+    const int i = b0 + tid;
+    const bool valid = i < t.count;
+    int f = 0; bool left = false;
+    float c[3] = { 0.f, 0.f, 0.f };
+    if (valid) {
+      f = order[t.first + i];
+      for (int a = 0; a < 3; a++) c[a] = (lo[3 * f + a] + hi[3 * f + a]) * 0.5f;
+      left = sp.axis < 0 ? (i < sp.nLeft) : (sah_bin(c[sp.axis], base[sp.axis], scale[sp.axis]) < sp.bin);
+    }
+    const unsigned long long mL = __ballot(valid && left), mR = __ballot(valid && !left);
+    if (lane == 0) { sWave[0][wave] = __popcll(mL); sWave[1][wave] = __popcll(mR); }
+    __syncthreads();
+    if (valid) {
+      const int side = left ? 0 : 1;
+      int off = sBase[side];
+      for (int w = 0; w < wave; w++) off += sWave[side][w];
+      const unsigned long long m = left ? mL : mR;
+      off += __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      tmp[t.first + (left ? 0 : sp.nLeft) + off] = f;
+      for (int a = 0; a < 3; a++) { atomicMin(&sCb[side][0][a], float_to_ordered(c[a])); atomicMax(&sCb[side][1][a], float_to_ordered(c[a])); }
+    }
+    __syncthreads();
+    if (tid == 0) for (int s2 = 0; s2 < 2; s2++) { int tot = 0; for (int w = 0; w < kSahBlock / 64; w++) tot += sWave[s2][w]; sBase[s2] += tot; }
+    __syncthreads();
+  }
+  __threadfence_block();
+  for (int i = tid; i < t.count; i += kSahBlock) order[t.first + i] = tmp[t.first + i];
+  if (tid == 0) {
+    first[t.node] = t.first; last[t.node] = t.first + t.count - 1;
+    for (int s2 = 0; s2 < 2; s2++) {
+      SahTask ch; ch.node = -1; ch.first = t.first + (s2 ? sp.nLeft : 0); ch.count = s2 ? t.count - sp.nLeft : sp.nLeft;
+      for (int a = 0; a < 3; a++) { ch.cbLo[a] = ordered_to_float(sCb[s2][0][a]); ch.cbHi[a] = ordered_to_float(sCb[s2][1][a]); }
+      children[2 * (size_t)blockIdx.x + s2] = ch;
+    }
+  }
+}
+
+__global__ void k_sah_flags(int nChildren, const SahTask* __restrict__ children, int* __restrict__ flags) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nChildren) flags[c] = children[c].count >= 2 ? 1 : 0;
+}
+
+// children with two or more triangles become the next level's nodes, numbered in range order after this level's
+__global__ void k_sah_finalize(int nChildren, const SahTask* __restrict__ tasks, const SahTask* __restrict__ children,
+                               const int* __restrict__ flags, const int* __restrict__ offs, int nextBase,
+                               int* __restrict__ left, int* __restrict__ right, int* __restrict__ parentI, int* __restrict__ parentL,
+                               SahTask* __restrict__ nextTasks, int* nextCount) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nChildren) return;
+  const int node = tasks[c >> 1].node;
+  SahTask ch = children[c];
+  int ref;
+  if (flags[c]) { ref = nextBase + offs[c]; ch.node = ref; parentI[ref] = node; nextTasks[offs[c]] = ch; }
+  else { ref = ~ch.first; parentL[ch.first] = node; }
+  if (c & 1) right[node] = ref; else left[node] = ref;
+  if (c == nChildren - 1) *nextCount = offs[c] + flags[c];
+}
+
+__global__ void k_order_keys(int n, const int* __restrict__ order, uint64_t* __restrict__ keys) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) keys[k] = (uint64_t)(uint32_t)order[k];
+}
+
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -206,7 +324,7 @@ void lbvh_free(LbvhResult* r) {
 #define LB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
 
 hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dFaceNrm, const int* dFaceHasNrm,
-                      const int* dFaceMat, int n, int leafSize, LbvhResult* out) {
+                      const int* dFaceMat, int n, int leafSize, int builder, LbvhResult* out) {
   hipError_t err = hipSuccess;
   *out = LbvhResult();
   out->nTris = n; out->leafSize = leafSize;
@@ -220,6 +338,9 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
   uint64_t *keys = nullptr, *keysSorted = nullptr;
   int *left = nullptr, *right = nullptr, *first = nullptr, *last = nullptr, *parentI = nullptr, *parentL = nullptr, *kept = nullptr, *newIndex = nullptr, *opened = nullptr;
   unsigned int* arrivals = nullptr; SceneBox* box = nullptr; int* dDepth = nullptr; void* tmp = nullptr;
+  int *order = nullptr, *orderTmp = nullptr, *sahFlags = nullptr, *sahOffs = nullptr, *sahNext = nullptr;
+  SahTask *tasksA = nullptr, *tasksB = nullptr, *sahChildren = nullptr;
+  size_t tmpSah = 0;
   size_t tmpSort = 0, tmpScan = 0, tmpBytes = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int hostCount[2] = { 0, 0 };
@@ -235,6 +356,13 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
   LB_CHECK(dmalloc(&out->tris, (size_t)n)); LB_CHECK(dmalloc(&out->shade, (size_t)n));
   LB_CHECK(rocprim::radix_sort_keys(nullptr, tmpSort, keys, keysSorted, (size_t)n, 0, 64, stream));
   if (ni > 0) LB_CHECK(rocprim::exclusive_scan(nullptr, tmpScan, kept, newIndex, 0, (size_t)ni, rocprim::plus<int>(), stream));
+  if (builder == 1 && n > leafSize) {
+    LB_CHECK(dmalloc(&order, (size_t)n)); LB_CHECK(dmalloc(&orderTmp, (size_t)n));
+    LB_CHECK(dmalloc(&sahFlags, (size_t)n + 2)); LB_CHECK(dmalloc(&sahOffs, (size_t)n + 2)); LB_CHECK(dmalloc(&sahNext, 1));
+    LB_CHECK(dmalloc(&tasksA, (size_t)n / 2 + 2)); LB_CHECK(dmalloc(&tasksB, (size_t)n / 2 + 2)); LB_CHECK(dmalloc(&sahChildren, (size_t)n + 2));
+    LB_CHECK(rocprim::exclusive_scan(nullptr, tmpSah, sahFlags, sahOffs, 0, (size_t)n + 2, rocprim::plus<int>(), stream));
+    if (tmpSah > tmpScan) tmpScan = tmpSah;
+  }
   tmpBytes = tmpSort > tmpScan ? tmpSort : tmpScan;
   LB_CHECK(hipMalloc(&tmp, tmpBytes ? tmpBytes : 16));
 
@@ -243,6 +371,28 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
   k_bounds<<<grid_for(n), kBlock, 0, stream>>>(n, dFacePos, lo, hi, box);
   k_morton<<<grid_for(n), kBlock, 0, stream>>>(n, lo, hi, box, keys);
   LB_CHECK(rocprim::radix_sort_keys(tmp, tmpSort, keys, keysSorted, (size_t)n, 0, 64, stream));
+  if (builder == 1 && n > leafSize) {
+    // binned-SAH topology over the Morton order, one launch per level (pt_lbvh.h); the final order replaces the keys
+    k_sah_init<<<grid_for(n), kBlock, 0, stream>>>(n, keysSorted, order, tasksA, box);
+    LB_CHECK(hipMemsetAsync(parentI, 0xff, sizeof(int) * (size_t)ni, stream));          // root: parent -1
+    int nActive = 1, idBase = 0, level = 0;
+    SahTask *cur = tasksA, *nxt = tasksB;
+    while (nActive > 0) {
+      const int nChildren = 2 * nActive;
+      k_sah_level<<<nActive, kSahBlock, 0, stream>>>(cur, leafSize, level < kSahLevels ? 1 : 0, lo, hi, order, orderTmp, first, last, sahChildren);
+      k_sah_flags<<<grid_for(nChildren), kBlock, 0, stream>>>(nChildren, sahChildren, sahFlags);
+      size_t tb = tmpBytes;
+      LB_CHECK(rocprim::exclusive_scan(tmp, tb, sahFlags, sahOffs, 0, (size_t)nChildren, rocprim::plus<int>(), stream));
+      k_sah_finalize<<<grid_for(nChildren), kBlock, 0, stream>>>(nChildren, cur, sahChildren, sahFlags, sahOffs, idBase + nActive,
+                                                                left, right, parentI, parentL, nxt, sahNext);
+      int nextActive = 0;
+      LB_CHECK(hipMemcpyAsync(&nextActive, sahNext, sizeof(int), hipMemcpyDeviceToHost, stream));
+      LB_CHECK(hipStreamSynchronize(stream));
+      idBase += nActive; nActive = nextActive; level++;
+      SahTask* sw = cur; cur = nxt; nxt = sw;
+    }
+    k_order_keys<<<grid_for(n), kBlock, 0, stream>>>(n, order, keysSorted);
+  }
   k_leaves<<<grid_for(n), kBlock, 0, stream>>>(n, keysSorted, dFacePos, dFaceNrm, dFaceHasNrm, dFaceMat, lo, hi, box,
                                                out->tris, out->shade, leafLo, leafHi);
   if (n <= leafSize) {
@@ -251,7 +401,7 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
   } else {
     LB_CHECK(hipMemsetAsync(arrivals, 0, sizeof(unsigned int) * (size_t)ni, stream));
     LB_CHECK(hipMemsetAsync(dDepth, 0, sizeof(int), stream));
-    k_karras<<<grid_for(ni), kBlock, 0, stream>>>(n, keysSorted, left, right, first, last, parentI, parentL);
+    if (builder != 1) k_karras<<<grid_for(ni), kBlock, 0, stream>>>(n, keysSorted, left, right, first, last, parentI, parentL);
     k_fit<<<grid_for(n), kBlock, 0, stream>>>(n, left, right, parentI, parentL, leafLo, leafHi, ilo, ihi, arrivals);
     k_opened<<<grid_for(ni), kBlock, 0, stream>>>(ni, left, right, first, last, leafSize, ilo, ihi, opened);
     k_kept<<<(ni + 63) / 64, 64, 0, stream>>>(ni, first, last, parentI, leafSize, opened, kept, dDepth);
@@ -274,7 +424,8 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
 done:
   for (void* p : { (void*)lo, (void*)hi, (void*)leafLo, (void*)leafHi, (void*)ilo, (void*)ihi, (void*)keys, (void*)keysSorted,
                    (void*)left, (void*)right, (void*)first, (void*)last, (void*)parentI, (void*)parentL, (void*)kept, (void*)newIndex,
-                   (void*)arrivals, (void*)box, (void*)dDepth, (void*)opened, tmp })
+                   (void*)arrivals, (void*)box, (void*)dDepth, (void*)opened, tmp, (void*)order, (void*)orderTmp, (void*)sahFlags,
+                   (void*)sahOffs, (void*)sahNext, (void*)tasksA, (void*)tasksB, (void*)sahChildren })
     if (p) (void)hipFree(p);
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);

@@ -81,6 +81,7 @@ struct moptix_context_t {
   std::vector<int> seedStaging;
   int optWatchdogMs = 600000;
   int optFastShading = 0;
+  int optBuilder = 1;
   double kernelMs = 0.0, reduceMs = 0.0; uint64_t nLaunches = 0;
   bool asyncPending = false;
 };
@@ -508,7 +509,7 @@ int moptix_build_accel(moptix_context c, const char* kind) {
     HIPCHK(c, c->dFaceNrm.upload(c->faceNrm, c->stream), "upload face normals");
     HIPCHK(c, c->dFaceHasNrm.upload(c->faceHasNrm, c->stream), "upload face flags");
     HIPCHK(c, c->dFaceMat.upload(c->faceMat, c->stream), "upload face materials");
-    HIPCHK(c, lbvh_build(c->stream, c->dFacePos.p, c->dFaceNrm.p, c->dFaceHasNrm.p, c->dFaceMat.p, nFaces, c->optLeafSize, &c->bvh), "LBVH build");
+    HIPCHK(c, lbvh_build(c->stream, c->dFacePos.p, c->dFaceNrm.p, c->dFaceHasNrm.p, c->dFaceMat.p, nFaces, c->optLeafSize, c->optBuilder, &c->bvh), "LBVH build");
   }
   HIPCHK(c, hipStreamSynchronize(c->stream), "sync after upload");
   c->sceneDirty = false; c->accelBuilt = true;
@@ -578,6 +579,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "refill_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "refill_lanes in [1,64]"); c->optRefillLanes = value; }
   else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
   else if (!strcmp(name, "tile_major")) { if (value < 0 || value > 3) return fail(c, MOPTIX_ERR_INVALID, "tile_major in {0,1,2,3}"); c->optTileMajor = value; }
+  else if (!strcmp(name, "builder")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "builder in {0,1}"); if (value != c->optBuilder) c->accelBuilt = false; c->optBuilder = value; }
   else if (!strcmp(name, "fast_shading")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "fast_shading in {0,1}"); c->optFastShading = value; }
   else if (!strcmp(name, "watchdog_ms")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "watchdog_ms >= 1"); c->optWatchdogMs = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
@@ -599,6 +601,7 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "tile_major")) *value = c->optTileMajor;
   else if (!strcmp(name, "watchdog_ms")) *value = c->optWatchdogMs;
   else if (!strcmp(name, "fast_shading")) *value = c->optFastShading;
+  else if (!strcmp(name, "builder")) *value = c->optBuilder;
   else if (!strcmp(name, "num_cus")) *value = c->numCUs;
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;

@@ -65,6 +65,67 @@ PT_HD int lcp(const uint64_t* keys, int n, int i, int j) {
   return clz64(keys[i] ^ keys[j]);
 }
 
+PT_HD float half_area(const float* lo, const float* hi) {
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  return (dx * dy + dy * dz) + dz * dx;
+}
+// ---------------------------------------------------------------------------------------------------------------
+// Binned-SAH topology ("Trbvh" asks OptiX for a high-quality tree; a plain Morton radix tree needs 9.7 node fetches
+// per ray on the coffee scene where a surface-area-heuristic tree needs 7.5).  Same array form as the Karras tree
+// (left / right / first / last / parent over the triangles in a final order, leaves = single triangles), so the box
+// fit, the collapse, the widening and the emission below are shared.  Built level by level, top down:
+//   * the triangles start in Morton order (locality for the passes that follow);
+//   * a node with more than leafSize triangles bins the centroids of its range into kSahBins bins per axis inside
+//     the range's centroid box, sweeps the 3 x (kSahBins-1) candidate planes and takes the cheapest
+//     area(left) * count(left) + area(right) * count(right) (first one in sweep order on a tie); its range is
+//     partitioned STABLY by "bin < plane";
+//   * a node whose centroids coincide, every node with <= leafSize triangles (they are collapsed into leaves
+//     later, the levels below only complete the array form) and every node below level kSahLevels splits its range
+//     in the middle;
+//   * nodes are numbered breadth first, children in range order.
+// min / max / counts are exact and the sweep is one sequential function, so the tree is a pure function of the
+// input: tests/hostsim runs the same functions on the host and the GPU tests compare the trees word for word.
+constexpr int kSahBins = 16;
+constexpr int kSahLevels = 40;         // deeper levels split in the middle: bounds the depth at 40 + log2(n) <= 64 (wide_level's path)
+struct SahBins {                       // per axis and bin: box of the triangles (order-preserving uints) + their number
+  uint32_t lo[3][kSahBins][3], hi[3][kSahBins][3];
+  int cnt[3][kSahBins];
+};
+struct SahSplit { int axis, bin, nLeft; };          // axis < 0: split the range in the middle
+PT_HD float sah_scale(float lo, float hi) { const float e = hi - lo; return e > 0.0f ? (float)kSahBins / e : 0.0f; }
+PT_HD int sah_bin(float c, float lo, float scale) {
+  int b = (int)((c - lo) * scale);
+  return b < 0 ? 0 : (b >= kSahBins ? kSahBins - 1 : b);
+}
+PT_HD SahSplit sah_choose(const SahBins& B, v3 cbLo, v3 cbHi, int count) {
+  SahSplit best; best.axis = -1; best.bin = 0; best.nLeft = (count + 1) / 2;
+  float bestCost = 3.0e38f;
+  const float ext[3] = { cbHi.x - cbLo.x, cbHi.y - cbLo.y, cbHi.z - cbLo.z };
+  for (int a = 0; a < 3; a++) {
+    if (!(ext[a] > 0.0f)) continue;
+    float la[kSahBins]; int lc[kSahBins];
+    float l0[3] = { 1e37f, 1e37f, 1e37f }, l1[3] = { -1e37f, -1e37f, -1e37f };
+    int c = 0;
+    for (int i = 0; i < kSahBins; i++) {
+      if (B.cnt[a][i] > 0)
+        for (int k = 0; k < 3; k++) { l0[k] = fminf_(l0[k], ordered_to_float(B.lo[a][i][k])); l1[k] = fmaxf_(l1[k], ordered_to_float(B.hi[a][i][k])); }
+      c += B.cnt[a][i];
+      la[i] = c > 0 ? half_area(l0, l1) : 0.0f; lc[i] = c;
+    }
+    float r0[3] = { 1e37f, 1e37f, 1e37f }, r1[3] = { -1e37f, -1e37f, -1e37f };
+    c = 0;
+    for (int i = kSahBins - 1; i >= 1; i--) {
+      if (B.cnt[a][i] > 0)
+        for (int k = 0; k < 3; k++) { r0[k] = fminf_(r0[k], ordered_to_float(B.lo[a][i][k])); r1[k] = fmaxf_(r1[k], ordered_to_float(B.hi[a][i][k])); }
+      c += B.cnt[a][i];
+      if (c == 0 || lc[i - 1] == 0) continue;
+      const float cost = la[i - 1] * (float)lc[i - 1] + half_area(r0, r1) * (float)c;
+      if (cost < bestCost) { bestCost = cost; best.axis = a; best.bin = i; best.nLeft = lc[i - 1]; }
+    }
+  }
+  return best;
+}
+
 // child reference inside the *uncollapsed* Karras tree: >=0 internal node, <0 -> ~sortedLeaf
 struct KarrasNode { int left, right, first, last; };
 
@@ -112,10 +173,6 @@ PT_HD int collapsed_ref(int child, const int* first, const int* last, const int*
 // order kept).  Opened nodes disappear; the surviving children that are left become wide nodes themselves.
 PT_HD bool karras_kept(int c, const int* first, const int* last, int leafSize) {
   return c >= 0 && last[c] - first[c] + 1 > leafSize;
-}
-PT_HD float half_area(const float* lo, const float* hi) {
-  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-  return (dx * dy + dy * dz) + dz * dx;
 }
 // Karras children (>=0 internal, <0 leaf) of wide node r, left to right; opened[] receives the absorbed nodes
 PT_HD int wide_children(int r, const int* left, const int* right, const int* first, const int* last, int leafSize,

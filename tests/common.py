@@ -95,13 +95,16 @@ def hostsim_render(hs, seeds, leaf_size=4, accum=None):
     return accum, out
 
 
-def hostsim_bvh(hs, leaf_size=4):
+def hostsim_bvh(hs, leaf_size=4, builder=1):
+    """builder: 0 = Morton radix tree, 1 = binned SAH (the device default; moptix option "builder")."""
+    hostsim_lib().hostsim_set_builder(int(builder))
     s, keep = _hostsim_scene(hs)
     nf = max(1, s.nFaces)
     nodes = np.zeros((nf, 32), np.uint32); tris = np.zeros((nf, 12), np.uint32); prim = np.zeros(nf, np.int32)
     out = HostsimBvhOut()
     out.nodes, out.tris, out.triPrim = nodes.ctypes.data, tris.ctypes.data, prim.ctypes.data_as(C.POINTER(C.c_int32))
     rc = hostsim_lib().hostsim_build_bvh(C.byref(s), leaf_size, C.byref(out))
+    hostsim_lib().hostsim_set_builder(1)
     assert rc == 0
     return nodes[:out.nNodes], tris[:s.nFaces], prim[:s.nFaces], out.rootRef, out.depth
 

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 #include <omp.h>
@@ -64,49 +65,69 @@ static int subtree_depth(const std::vector<Node128>& nodes, int ref) {
   return best;
 }
 
-// Experiment only (HOSTSIM_SAH=1): top-down binned-SAH binary tree in the same array form as the Karras tree,
-// to measure how much a better tree would save in node fetches / triangle tests.
-struct SahBuilder {
-  const std::vector<v3>&lo, &hi, &cen; std::vector<int> ids; std::vector<KarrasNode> nodes;
-  static float area(v3 a, v3 b) { const v3 d = b - a; return d.x * d.y + d.y * d.z + d.z * d.x; }
-  static float comp(v3 v, int a) { return a == 0 ? v.x : a == 1 ? v.y : v.z; }
-  int build(int b, int e) {   // returns child ref: >=0 node, <0 ~position
-    if (e - b == 1) return ~b;
-    const int id = (int)nodes.size(); nodes.push_back(KarrasNode{ 0, 0, b, e - 1 });
-    v3 clo = mk3(1e37f, 1e37f, 1e37f), chi = mk3(-1e37f, -1e37f, -1e37f);
-    for (int k = b; k < e; k++) { const v3 c = cen[ids[k]];
-      clo = mk3(fminf_(clo.x, c.x), fminf_(clo.y, c.y), fminf_(clo.z, c.z)); chi = mk3(fmaxf_(chi.x, c.x), fmaxf_(chi.y, c.y), fmaxf_(chi.z, c.z)); }
-    const int NB = 16; float bestCost = 1e38f; int bestAxis = -1, bestBin = -1;
-    for (int a = 0; a < 3; a++) {
-      const float ext = comp(chi, a) - comp(clo, a);
-      if (!(ext > 0.f)) continue;
-      v3 blo[NB], bhi[NB]; int cnt[NB];
-      for (int i = 0; i < NB; i++) { blo[i] = mk3(1e37f, 1e37f, 1e37f); bhi[i] = mk3(-1e37f, -1e37f, -1e37f); cnt[i] = 0; }
-      for (int k = b; k < e; k++) { const int f = ids[k];
-        int bi = (int)((comp(cen[f], a) - comp(clo, a)) / ext * NB); if (bi >= NB) bi = NB - 1; if (bi < 0) bi = 0;
-        cnt[bi]++; blo[bi] = mk3(fminf_(blo[bi].x, lo[f].x), fminf_(blo[bi].y, lo[f].y), fminf_(blo[bi].z, lo[f].z));
-        bhi[bi] = mk3(fmaxf_(bhi[bi].x, hi[f].x), fmaxf_(bhi[bi].y, hi[f].y), fmaxf_(bhi[bi].z, hi[f].z)); }
-      float la[NB]; int lc[NB]; v3 l0 = mk3(1e37f, 1e37f, 1e37f), l1 = mk3(-1e37f, -1e37f, -1e37f); int c = 0;
-      for (int i = 0; i < NB; i++) { if (cnt[i]) { l0 = mk3(fminf_(l0.x, blo[i].x), fminf_(l0.y, blo[i].y), fminf_(l0.z, blo[i].z)); l1 = mk3(fmaxf_(l1.x, bhi[i].x), fmaxf_(l1.y, bhi[i].y), fmaxf_(l1.z, bhi[i].z)); } c += cnt[i]; la[i] = c ? area(l0, l1) : 0.f; lc[i] = c; }
-      v3 r0 = mk3(1e37f, 1e37f, 1e37f), r1 = mk3(-1e37f, -1e37f, -1e37f); c = 0;
-      for (int i = NB - 1; i >= 1; i--) { if (cnt[i]) { r0 = mk3(fminf_(r0.x, blo[i].x), fminf_(r0.y, blo[i].y), fminf_(r0.z, blo[i].z)); r1 = mk3(fmaxf_(r1.x, bhi[i].x), fmaxf_(r1.y, bhi[i].y), fmaxf_(r1.z, bhi[i].z)); } c += cnt[i];
-        if (c == 0 || lc[i - 1] == 0) continue;
-        const float cost = la[i - 1] * lc[i - 1] + area(r0, r1) * c;
-        if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = i; } }
+// Host mirror of the device's binned-SAH topology (lbvh.hip k_sah_level / k_sah_finalize; shared functions and the
+// definition of the algorithm: pt_lbvh.h).  order: Morton order on entry, final order on return; nodes: n-1 entries.
+struct SahTask { int node, first, count; v3 cbLo, cbHi; };
+static void build_sah_topology(const std::vector<v3>& lo, const std::vector<v3>& hi, std::vector<int>& order, v3 cbLo, v3 cbHi,
+                               int leafSize, std::vector<KarrasNode>& nodes, std::vector<int>& parentI, std::vector<int>& parentL) {
+  const int n = (int)order.size();
+  nodes.assign(n - 1, KarrasNode{ 0, 0, 0, 0 }); parentI.assign(n - 1, -1); parentL.assign(n, -1);
+  std::vector<SahTask> tasks{ SahTask{ 0, 0, n, cbLo, cbHi } }, next;
+  int idBase = 0, level = 0;
+  std::vector<int> tmp(n);
+  while (!tasks.empty()) {
+    next.clear();
+    if (getenv("HOSTSIM_DEBUG")) fprintf(stderr, "[hostsim] SAH level %d: %zu nodes\n", level, tasks.size());
+    const int nextBase = idBase + (int)tasks.size();
+    for (const SahTask& t : tasks) {
+      SahSplit sp; sp.axis = -1; sp.bin = 0; sp.nLeft = (t.count + 1) / 2;
+      const float scale[3] = { sah_scale(t.cbLo.x, t.cbHi.x), sah_scale(t.cbLo.y, t.cbHi.y), sah_scale(t.cbLo.z, t.cbHi.z) };
+      const float base[3] = { t.cbLo.x, t.cbLo.y, t.cbLo.z };
+      auto cen = [&](int f, int a) { const v3 c = (lo[f] + hi[f]) * 0.5f; return a == 0 ? c.x : a == 1 ? c.y : c.z; };
+      if (t.count > leafSize && level < kSahLevels) {
+        SahBins B;
+        for (int a = 0; a < 3; a++) for (int b = 0; b < kSahBins; b++) { B.cnt[a][b] = 0; for (int k = 0; k < 3; k++) { B.lo[a][b][k] = float_to_ordered(1e37f); B.hi[a][b][k] = float_to_ordered(-1e37f); } }
+        for (int i = 0; i < t.count; i++) {
+          const int f = order[t.first + i];
+          const float l[3] = { lo[f].x, lo[f].y, lo[f].z }, h[3] = { hi[f].x, hi[f].y, hi[f].z };
+          for (int a = 0; a < 3; a++) {
+            const int b = sah_bin(cen(f, a), base[a], scale[a]);
+            B.cnt[a][b]++;
+            for (int k = 0; k < 3; k++) { B.lo[a][b][k] = std::min(B.lo[a][b][k], float_to_ordered(l[k])); B.hi[a][b][k] = std::max(B.hi[a][b][k], float_to_ordered(h[k])); }
+          }
+        }
+        sp = sah_choose(B, t.cbLo, t.cbHi, t.count);
+      }
+      // stable partition of the range + centroid boxes of the two halves
+      int nl = 0, nr = 0;
+      v3 cl[2] = { mk3(1e37f, 1e37f, 1e37f), mk3(1e37f, 1e37f, 1e37f) }, ch[2] = { mk3(-1e37f, -1e37f, -1e37f), mk3(-1e37f, -1e37f, -1e37f) };
+      for (int i = 0; i < t.count; i++) {
+        const int f = order[t.first + i];
+        const bool left = sp.axis < 0 ? (i < sp.nLeft) : (sah_bin(cen(f, sp.axis), base[sp.axis], scale[sp.axis]) < sp.bin);
+        const int side = left ? 0 : 1;
+        tmp[t.first + (left ? nl++ : sp.nLeft + nr++)] = f;
+        const v3 c = (lo[f] + hi[f]) * 0.5f;
+        cl[side] = mk3(fminf_(cl[side].x, c.x), fminf_(cl[side].y, c.y), fminf_(cl[side].z, c.z));
+        ch[side] = mk3(fmaxf_(ch[side].x, c.x), fmaxf_(ch[side].y, c.y), fmaxf_(ch[side].z, c.z));
+      }
+      for (int i = 0; i < t.count; i++) order[t.first + i] = tmp[t.first + i];
+      KarrasNode& kn = nodes[t.node];
+      kn.first = t.first; kn.last = t.first + t.count - 1;
+      const int cf[2] = { t.first, t.first + sp.nLeft }, cc[2] = { sp.nLeft, t.count - sp.nLeft };
+      for (int side = 0; side < 2; side++) {
+        int ref;
+        if (cc[side] == 1) { ref = ~cf[side]; parentL[cf[side]] = t.node; }
+        else { ref = nextBase + (int)next.size(); parentI[ref] = t.node; next.push_back(SahTask{ ref, cf[side], cc[side], cl[side], ch[side] }); }
+        (side == 0 ? kn.left : kn.right) = ref;
+      }
     }
-    int mid;
-    if (bestAxis < 0) mid = (b + e) / 2;
-    else {
-      const float ext = comp(chi, bestAxis) - comp(clo, bestAxis), base = comp(clo, bestAxis);
-      auto binOf = [&](int f) { int bi = (int)((comp(cen[f], bestAxis) - base) / ext * NB); if (bi >= NB) bi = NB - 1; if (bi < 0) bi = 0; return bi; };
-      mid = (int)(std::stable_partition(ids.begin() + b, ids.begin() + e, [&](int f) { return binOf(f) < bestBin; }) - ids.begin());
-      if (mid == b || mid == e) mid = (b + e) / 2;
-    }
-    const int l = build(b, mid); const int r = build(mid, e);
-    nodes[id].left = l; nodes[id].right = r;
-    return id;
+    idBase = nextBase;
+    tasks.swap(next);
+    level++;
   }
-};
+}
+
+static int g_builder = 1;     // 0 = Morton radix tree (Karras), 1 = binned SAH over the Morton order (device default)
 
 static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   const int n = s.nFaces;
@@ -130,12 +151,13 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   const int idxBits = lbvh_index_bits(n), bitsPerAxis = getenv("HOSTSIM_MORTON30") ? 10 : lbvh_bits_per_axis(n);
   for (int f = 0; f < n; f++) keys[f] = morton_key(cen[f], clo, invExt, bitsPerAxis, idxBits, f);
   std::sort(keys.begin(), keys.end());
-  SahBuilder sah{ lo, hi, cen, {}, {} };
-  const bool useSah = getenv("HOSTSIM_SAH") != nullptr && n > 1;
+  std::vector<KarrasNode> sahNodes; std::vector<int> sahParentI, sahParentL;
+  const bool useSah = g_builder == 1 && n > 1;
   if (useSah) {
-    sah.ids.resize(n); for (int k = 0; k < n; k++) sah.ids[k] = key_face(keys[k], idxBits);
-    sah.build(0, n);
-    for (int k = 0; k < n; k++) keys[k] = ((uint64_t)k << idxBits) | (uint64_t)sah.ids[k];
+    std::vector<int> order(n);
+    for (int k = 0; k < n; k++) order[k] = key_face(keys[k], idxBits);
+    build_sah_topology(lo, hi, order, clo, chi, leafSize, sahNodes, sahParentI, sahParentL);
+    for (int k = 0; k < n; k++) keys[k] = (uint64_t)order[k];              // the device keeps the face index only, too
   }
 
   out.tris.resize(n); out.shade.resize(n);
@@ -161,7 +183,7 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   const int ni = n - 1;
   std::vector<KarrasNode> kn(ni);
   std::vector<int> first(ni), last(ni);
-  for (int i = 0; i < ni; i++) { kn[i] = useSah ? sah.nodes[i] : karras_node(keys.data(), n, i); first[i] = kn[i].first; last[i] = kn[i].last; }
+  for (int i = 0; i < ni; i++) { kn[i] = useSah ? sahNodes[i] : karras_node(keys.data(), n, i); first[i] = kn[i].first; last[i] = kn[i].last; }
   // boxes of every Karras node = union of the leaf boxes in its range (what the device's
   // bottom-up atomic pass produces; min/max are exact so the order does not matter)
   std::vector<v3> ilo(ni), ihi(ni);
@@ -275,6 +297,8 @@ static void make_scene(const hostsim_scene& s, int leafSize, HostScene& hs) {
 }  // namespace
 
 extern "C" {
+
+void hostsim_set_builder(int builder) { g_builder = builder; }
 
 int hostsim_build_bvh(const hostsim_scene* s, int leafSize, hostsim_bvh_out* out) {
   HostBVH b; build_lbvh(*s, leafSize, b);

@@ -103,13 +103,20 @@ def test_launch_by_launch_equals_fused(gpu_ctx):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("builder", [1, 0])
 @pytest.mark.parametrize("leaf", [1, 4, 8])
-def test_device_lbvh_equals_host_mirror(gpu_ctx, leaf):
+def test_device_lbvh_equals_host_mirror(gpu_ctx, leaf, builder):
+    """The device build (builder 1: binned-SAH topology over the Morton order, the default; builder 0: Morton radix
+    tree) is a pure function of its input: the sequential host mirror gives the same nodes and records word for word."""
     hs = M.HostScene("file:coffee", 64, 36)
     gpu_ctx.set_option("leaf_size", leaf)
-    gpu_ctx.load(hs)
-    nodes, tris, prim = gpu_ctx.debug_read_accel()
-    hn, ht, hp, root, depth = hostsim_bvh(hs, leaf)
+    gpu_ctx.set_option("builder", builder)
+    try:
+        gpu_ctx.load(hs)
+        nodes, tris, prim = gpu_ctx.debug_read_accel()
+    finally:
+        gpu_ctx.set_option("builder", 1)
+    hn, ht, hp, root, depth = hostsim_bvh(hs, leaf, builder)
     info = gpu_ctx.accel_info()
     assert info.nNodes == len(hn) and info.treeDepth == depth
     assert np.array_equal(prim, hp)

@@ -21,10 +21,11 @@ def test_flattened_state_machine_equals_recursive_oracle(kind, kw, res, spp):
            (ost.primaryRays, ost.bounceRays, ost.shadowRays, ost.closestHits)
 
 
+@pytest.mark.parametrize("builder", [1, 0])
 @pytest.mark.parametrize("leaf", [1, 4, 8])
-def test_lbvh_mirror_is_a_valid_bvh(leaf):
+def test_lbvh_mirror_is_a_valid_bvh(leaf, builder):
     hs = M.HostScene("file:coffee", 64, 36)
-    nodes, tris, prim, root, depth = hostsim_bvh(hs, leaf)
+    nodes, tris, prim, root, depth = hostsim_bvh(hs, leaf, builder)
     n = hs.sizes.nFaces
     assert sorted(prim.tolist()) == list(range(n))                       # every face exactly once
     assert root == 0 and 5 < depth < 32
@@ -54,6 +55,22 @@ def test_lbvh_mirror_is_a_valid_bvh(leaf):
             f, k = (~ref) >> 3, ((~ref) & 7) + 1
             v = np.concatenate([p0[f:f + k], p0[f:f + k] + e0[f:f + k], p0[f:f + k] - e1[f:f + k]])
             assert (v >= lo - 1e-6).all() and (v <= hi + 1e-6).all()
+
+
+def test_sah_topology_needs_fewer_node_fetches_and_gives_the_same_image():
+    """The binned-SAH topology (what the reference gets from "Trbvh") against the plain Morton radix tree: same bits
+    (the hit is independent of the tree), at least 15 % fewer four-wide node fetches per ray on the coffee scene."""
+    from common import hostsim_lib
+    hs = M.HostScene("file:coffee", 160, 90)
+    seeds = M.launch_seeds(2)
+    try:
+        hostsim_lib().hostsim_set_builder(0)
+        a, ca = hostsim_render(hs, seeds)
+    finally:
+        hostsim_lib().hostsim_set_builder(1)
+    b, cb = hostsim_render(hs, seeds)
+    assert np.array_equal(a, b)
+    assert cb["nodeFetches"] < 0.85 * ca["nodeFetches"] and cb["triTests"] <= ca["triTests"]
 
 
 def test_leaf_size_does_not_change_the_image():
