@@ -137,8 +137,8 @@ int check_ready(moptix_context c) {
 }
 
 int read_stats(moptix_context c, moptix_stats* stats) {
-  unsigned long long h[40];
-  HIPCHK(c, hipMemcpy(h, c->dCounters.p, sizeof(h), hipMemcpyDeviceToHost), "read counters");
+  unsigned long long h[40 + 768];
+  HIPCHK(c, hipMemcpy(h, c->dCounters.p, sizeof(unsigned long long) * (c->dCounters.n >= 808 ? 808 : 40), hipMemcpyDeviceToHost), "read counters");
   stats->samples = h[0]; stats->primaryRays = h[1]; stats->bounceRays = h[2]; stats->shadowRays = h[3];
   stats->nodeFetches = h[4]; stats->triTests = h[5]; stats->closestHits = h[6]; stats->lightLoads = h[7];
   stats->analyticTests = h[8]; stats->traversalSteps = h[9]; stats->activeLaneSteps = h[10];
@@ -154,6 +154,14 @@ int read_stats(moptix_context c, moptix_stats* stats) {
                        100 * h[28] / tt, 100 * h[29] / tt, 100 * h[30] / tt, h[32], h[31], tt / (double)h[32]);
     if (h[38]) fprintf(stderr, "[moptix] timeline (100 MHz clock): items ran out %.2f ms after the first wave started, last wave left %.2f ms after that\n",
                        (double)(h[37] - h[36]) * 1e-5, (double)(h[38] - h[37]) * 1e-5);
+    if (h[38] && c->dCounters.n >= 808) {
+      int lastB = 0; for (int b = 0; b < 256; b++) if (h[40 + b]) lastB = b;
+      const int ranOut = (int)((double)(h[37] - h[36]) * 1e-5);
+      fprintf(stderr, "[moptix] samples finishing per ms from the moment the items ran out (count, mean depth, max depth):");
+      for (int b = ranOut > 2 ? ranOut - 2 : 0; b <= lastB; b++)
+        fprintf(stderr, " [%d: %llu %.1f %llu]", b, h[40 + b], h[40 + b] ? (double)h[552 + b] / (double)h[40 + b] : 0.0, h[296 + b]);
+      fprintf(stderr, "\n");
+    }
     if (h[39]) fprintf(stderr, "[moptix] node runs %llu: node-ready slots waiting in the wave's ring %.1f, leaf ring %.1f (averages at the start of a run)\n",
                        h[39], (double)h[15] / (double)h[39], (double)h[13] / (double)h[39]);
     if (h[32]) fprintf(stderr, "[moptix] batch iterations executing on_result %llu, on_lights %llu, new item %llu (batches %llu)\n", h[33], h[34], h[35], h[11]);
@@ -247,8 +255,8 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   }
   a.workCounter = c->dWork.p;
   if (counted) {
-    HIPCHK(c, c->dCounters.ensure(40), "alloc counters");
-    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * 40, c->stream), "zero counters");
+    HIPCHK(c, c->dCounters.ensure(40 + 768), "alloc counters");
+    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * (40 + 768), c->stream), "zero counters");
     HIPCHK(c, hipMemsetAsync(c->dCounters.p + 36, 0xff, sizeof(unsigned long long) * 2, c->stream), "init min counters");
     a.counters = c->dCounters.p;
   }

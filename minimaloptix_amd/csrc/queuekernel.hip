@@ -372,6 +372,10 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBLoad); }
     for (;;) {
       if (have && ps.mode == M_NEW_SAMPLE) {
+        if (CNT) {      // finish-time histogram (1 ms buckets): how many samples end when, and how deep they were
+          const unsigned long long b = min(255ull, (__builtin_amdgcn_s_memrealtime() - rtStart) / 100000ull);
+          atomicAdd(a.counters + 40 + b, 1ull); atomicMax(a.counters + 296 + b, (unsigned long long)ps.depth); atomicAdd(a.counters + 552 + b, (unsigned long long)ps.depth);
+        }
         store_sample(a, ps.item, ps.accum);
         if (a.tileCost != nullptr && ps.depth >= kDeepPath) atomicMax(a.tileCost + ((ps.item % a.nItems) >> a.unitShift), (unsigned int)ps.depth);
         ps.mode = M_NEW_PIXEL;

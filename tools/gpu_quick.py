@@ -12,7 +12,11 @@ seeds = M.launch_seeds(spp)
 for o in os.environ.get("OPTS", "").split(","):
     if "=" in o:
         k, v = o.split("="); ctx.set_option(k, int(v))
+if os.environ.get("PART"):                      # PART=r/n: rank r's share of an n-way tile split
+    r_, n_ = os.environ["PART"].split("/"); ctx.set_partition(int(r_), int(n_))
 ctx.load(hs)
+for _ in range(int(os.environ.get("WARM", "0"))):   # history for the tile order
+    ctx.accum_clear(); ctx.render(seeds)
 ctx.accum_clear(); st = ctx.render_counted(seeds)
 rays = st.rays
 B = 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
