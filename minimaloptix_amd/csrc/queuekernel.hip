@@ -53,20 +53,20 @@ enum { Q_SHADE = 0, Q_GEN = 1, kNumQ = 2, Q_NODE = 2, Q_LEAF = 3, DEST_DONE = 4,
 // Path-slot record in HBM, private to the pool: eight 16-byte rows, grouped by WHO needs them and WHEN they change, so
 // that a visit moves only the rows it uses (round 1 moved all 144 bytes in and out on every shading visit and 48-80
 // bytes on every leaf visit: 474 B of scheduler state per ray, most of the kernel's fabric traffic):
-//   leaf pass                      reads dir (+ hit once a hit exists), writes hit only when the nearest hit changed
-//   shading, radiance ray back     reads ctl thr rad dir (+ hit)
+//   leaf pass                      reads hit once a hit exists, writes hit only when the nearest hit changed
+//   shading, radiance ray back     reads ctl thr rad (+ hit)
 //   shading, shadow ray back       reads ctl thr rad nrm view pend (+ hit = attenuation, once a glass surface was crossed)
-//   new shadow ray                 writes ctl rad dir pend, and nrm view only for the first light of a Disney hit
-//   new radiance ray               writes ctl dir, and thr / rad only if they changed
-// What the rows do not hold lives in the slot's LDS flag word (ray type, "hit row valid"), or is implied: the pixel
-// follows from the work item, tmin is the scene's epsilon, a radiance ray's tmax is RT_DEFAULT_MAX and a shadow ray's
-// tmax is the tbest the node loop carries (a shadow ray never shortens it).
+//   new shadow ray                 writes ctl rad pend, and nrm view only for the first light of a Disney hit
+//   new radiance ray               writes ctl, and thr / rad only if they changed
+// What the rows do not hold lives in LDS (origin, direction, tbest, node, stack; ray type and "hit row valid" in the
+// slot's flag word), or is implied: the pixel follows from the work item, tmin is the scene's epsilon, a radiance ray's
+// tmax is RT_DEFAULT_MAX and a shadow ray's tmax is the tbest the node loop carries (a shadow ray never shortens it).
 struct alignas(16) i4 { int x, y, z, w; };
 struct alignas(16) SlotCold {
   i4 ctl;     // item, depth, seed, mode | light << 3
   v4 thr;     // throughput, cdlin.y
   v4 rad;     // radiance so far, cdlin.z
-  v4 dir;     // d
+  v4 spare;
   v4 hit;     // radiance ray: bestTri, bestPrim (int bits), beta, gamma | shadow ray: attenuation
   v4 nrm;     // Disney hit context while its lights are looped: N, mat (int bits)
   v4 view;    // V, cdlin.x
@@ -108,7 +108,7 @@ template <int NS>
 struct PoolLds {
   // only what the node loop touches lives in LDS: 32 B + the stack per slot
   v4 nodeA[NS];           // o.xyz, tbest
-  v4 nodeB[NS];           // 1/d, node (int bits)
+  v4 nodeB[NS];           // d.xyz, node (int bits); a lane that picks the slot up for the node loop derives 1/d from it
   int stack[NS][kStackN + 1];   // [0] = sp | kShadeFlag, [1..] = entries
   unsigned short queue[kNumQ][ring_capacity(NS)];
   int qHead[kNumQ], qCount[kNumQ];   // SHARED only
@@ -147,6 +147,9 @@ struct SlotStack {
   }
 };
 
+__device__ __forceinline__ float node_inv(float d) {      // slab_inv (pt_path.h) with the hardware reciprocal
+  return __builtin_amdgcn_rcpf(__builtin_fabsf(d) < 1e-30f ? __builtin_copysignf(1e-30f, d) : d);
+}
 __device__ __forceinline__ int lane_rank(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
@@ -290,13 +293,12 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       LeafChunk ch;
       leaf_fetch4(sc, f2i(nb.w), 0, ch);
       const SlotCold* cs = cold + slot;
-      const v4 wd = slot_load(&cs->dir);
       v4 wh = mk4(0.f, 0.f, 0.f, 0.f);
       if (hitValid) wh = slot_load(&cs->hit);
-      ps.o = mk3(na.x, na.y, na.z); ps.d = mk3(wd.x, wd.y, wd.z);
+      ps.o = mk3(na.x, na.y, na.z); ps.d = mk3(nb.x, nb.y, nb.z);
       ps.kind = shadow ? RK_SHADOW : RK_RADIANCE;
       ps.tmax = shadow ? na.w : kRtDefaultMax;
-      tv.inv = mk3(nb.x, nb.y, nb.z); tv.tbest = na.w;
+      tv.inv = mk3(0.f, 0.f, 0.f); tv.tbest = na.w;      // the leaf step does not use 1/d
       tv.node = f2i(nb.w); tv.sp = fl & ~kSlotFlags;
       tv.bestTri = -1; tv.bestPrim = -1; tv.beta = 0.f; tv.gamma = 0.f; tv.att = mk3(1.f, 1.f, 1.f);
       if (hitValid) {
@@ -349,12 +351,11 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       const bool shadow = (fl & kShadowRay) != 0, hitValid = (fl & kHitValid) != 0;
       const i4 ctl = slot_load(&cs->ctl);
       thrIn = slot_load(&cs->thr); radIn = slot_load(&cs->rad);
-      v4 wd = mk4(0.f, 0.f, 1.f, 0.f), wh = mk4(0.f, 0.f, 0.f, 0.f);
+      v4 wh = mk4(0.f, 0.f, 0.f, 0.f);
       v4 wn = mk4(0.f, 0.f, 1.f, 0.f), wv = mk4(0.f, 0.f, 1.f, 0.f), wp = mk4(0.f, 0.f, 0.f, 0.f);
-      if (!shadow) wd = slot_load(&cs->dir);
       if (hitValid) wh = slot_load(&cs->hit);
       if (shadow) { wn = slot_load(&cs->nrm); wv = slot_load(&cs->view); wp = slot_load(&cs->pend); }
-      const v4 na = W.nodeA[slot];
+      const v4 na = W.nodeA[slot], wd = W.nodeB[slot];
       ps.mode = ctl.w & 7; ps.light = ctl.w >> 3; ps.item = ctl.x; ps.depth = ctl.y; ps.seed = (uint32_t)ctl.z; ps.pixel = 0;
       ps.thr = mk3(thrIn.x, thrIn.y, thrIn.z); ps.rad = mk3(radIn.x, radIn.y, radIn.z);
       ps.N = mk3(wn.x, wn.y, wn.z); ps.mat = f2i(wn.w); ps.V = mk3(wv.x, wv.y, wv.z);
@@ -423,12 +424,11 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         trav_begin<CNT>(sc, ps, tv, ct);
         v4 na, nb;
         na.x = ps.o.x; na.y = ps.o.y; na.z = ps.o.z; na.w = tv.tbest;
-        nb.x = tv.inv.x; nb.y = tv.inv.y; nb.z = tv.inv.z; nb.w = i2f(tv.node);
+        nb.x = ps.d.x; nb.y = ps.d.y; nb.z = ps.d.z; nb.w = i2f(tv.node);
         W.nodeA[slot] = na; W.nodeB[slot] = nb;
         const bool shadow = ps.kind == RK_SHADOW;
         const bool hitNow = shadow ? (tv.att.x != 1.f || tv.att.y != 1.f || tv.att.z != 1.f) : (tv.bestPrim >= 0);
         W.stack[slot][0] = ((shadow || tv.bestPrim >= 0) ? kShadeFlag : 0) | (shadow ? kShadowRay : 0) | (hitNow ? kHitValid : 0);
-        slot_store(&cw->dir, mk4(ps.d.x, ps.d.y, ps.d.z, 0.f));
         if (hitNow) slot_store(&cw->hit, shadow ? mk4(tv.att.x, tv.att.y, tv.att.z, 0.f) : mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma));
         if (shadow) {
           slot_store(&cw->pend, mk4(ps.pendW.x, ps.pendW.y, ps.pendW.z, ps.pendInv));
@@ -510,7 +510,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
             const v4 na = W.nodeA[ns], nb = W.nodeB[ns];
             const int spw = W.stack[ns][0];
             nray.o = mk3(na.x, na.y, na.z); ntv.tbest = na.w;
-            ntv.inv = mk3(nb.x, nb.y, nb.z); ntv.node = f2i(nb.w);
+            // 1/d by v_rcp_f32 (1 ulp): the slab test is conservative by far more than that (boxes are padded by 1e-5 of
+            // the scene, pt_lbvh.h pad_lo/pad_hi), and which boxes are entered never changes the result (rule D5)
+            ntv.inv = mk3(node_inv(nb.x), node_inv(nb.y), node_inv(nb.z)); ntv.node = f2i(nb.w);
             ntv.noi = neg_o_inv(nray.o, ntv.inv);
             ntv.sp = spw & ~kSlotFlags; nsFlag = spw & kSlotFlags;
           }
