@@ -232,10 +232,15 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     return st;
   };
 
-  // ---- start-up: every slot needs a work item ----
+  // ---- start-up: every slot in use needs a work item ----
+  // Paths in flight = slots in use; by Little's law a ray spends (slots in use) / (rays per second) in the scheduler,
+  // about 70 us with all 512 slots of every pool, so a path that bounces to the depth cap (about 1000 dependent rays)
+  // takes 70-90 ms however short the launch is.  A short launch (one rank's share of a multi-GPU frame) therefore
+  // uses fewer slots: a little less throughput, a much shorter critical path (LaunchArgs::slotsInUse, moptix_api.hip).
+  const int nUse = (a.slotsInUse > 0 && a.slotsInUse < NS) ? (SHARED ? a.slotsInUse : max(64, a.slotsInUse / kWaves)) : NS;
   {
     const int first = SHARED ? threadIdx.x : lane, step = SHARED ? kBlockThreads : 64;
-    for (int s = first; s < NS; s += step) {
+    for (int s = first; s < nUse; s += step) {
       i4 ctl; ctl.x = 0; ctl.y = 0; ctl.z = 0; ctl.w = M_NEW_PIXEL;
       cold[s].ctl = ctl;
       W.stack[s][0] = 0;
@@ -244,12 +249,12 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     if constexpr (SHARED) {
       if (threadIdx.x == 0) {
         for (int q = 0; q < kNumQ; q++) { W.qHead[q] = 0; W.qCount[q] = 0; }
-        W.qCount[Q_GEN] = NS; W.done = 0; W.lock = 0;
+        W.qCount[Q_GEN] = nUse; W.done = NS - nUse; W.lock = 0;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
     } else {
-      qCount[Q_GEN] = NS;
+      qCount[Q_GEN] = nUse; nDone = NS - nUse;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
   }

@@ -268,3 +268,19 @@ def test_fast_shading_mode_keeps_the_paths_and_moves_weights_by_1e_6(gpu_ctx):
     o, _ = oracle_scene(hs).render(seeds, region=(0, y0, W, y1), threads=THREADS)
     e = rmse(fast[y0:y1] / spp, o[y0:y1] / spp)
     assert e <= 1e-3 and e <= 1e-5, e
+
+
+def test_slots_in_use_is_a_scheduling_knob_only(gpu_ctx):
+    """A launch may use fewer of its path slots (a shorter critical path for a short launch, less throughput):
+    same bits either way."""
+    hs = M.HostScene("file:coffee", 320, 180)
+    seeds = M.launch_seeds(4)
+    gpu_ctx.load(hs)
+    ref, _ = _render(gpu_ctx, seeds)
+    try:
+        for n in (384, 200, 64):
+            gpu_ctx.set_option("slots_in_use", n)
+            got, _ = _render(gpu_ctx, seeds)
+            assert np.array_equal(got, ref), n
+    finally:
+        gpu_ctx.set_option("slots_in_use", -1)
