@@ -198,6 +198,137 @@ __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restri
   }
 }
 
+// 4''. the same level step for the top of the tree, where a handful of nodes hold most of the triangles: one thread
+// per triangle, bins and child centroid boxes by global atomics (exact min / max / counts: same result as the
+// workgroup-per-node form), the stable partition from one prefix sum over the "goes left" flags.
+__device__ __forceinline__ int sah_task_of(const SahTask* __restrict__ tasks, int nTasks, int pos) {   // tasks are sorted by range
+  int lo = 0, hi = nTasks - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tasks[mid].first <= pos) lo = mid; else hi = mid - 1; }
+  const SahTask& t = tasks[lo];
+  return (pos >= t.first && pos < t.first + t.count) ? lo : -1;
+}
+__global__ void k_sahw_clear(int nTasks, SahBins* bins, uint32_t* childCb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nTasks * 3 * kSahBins) {
+    const int t = i / (3 * kSahBins), r = i % (3 * kSahBins), a = r / kSahBins, b = r % kSahBins;
+    bins[t].cnt[a][b] = 0;
+    for (int k = 0; k < 3; k++) { bins[t].lo[a][b][k] = float_to_ordered(1e37f); bins[t].hi[a][b][k] = float_to_ordered(-1e37f); }
+  }
+  if (i < nTasks * 12) childCb[i] = float_to_ordered(((i / 3) & 1) ? -1e37f : 1e37f);     // [task][side][lo|hi][axis]
+}
+__global__ void k_sahw_bin(int n, const SahTask* __restrict__ tasks, int nTasks, int leafSize, const float* __restrict__ lo,
+                           const float* __restrict__ hi, const int* __restrict__ order, SahBins* bins) {
+  // A workgroup whose 256 positions lie in ONE node (almost all of them, at the top of the tree) bins into LDS and
+  // flushes 3 x 16 bins once; a workgroup across a range boundary goes to the global bins directly.
+  __shared__ SahBins B;
+  const int p0 = blockIdx.x * blockDim.x, p = p0 + threadIdx.x;
+  const int tFirst = sah_task_of(tasks, nTasks, p0), tLast = sah_task_of(tasks, nTasks, min(n, p0 + (int)blockDim.x) - 1);
+  const bool uniform = tFirst >= 0 && tFirst == tLast;
+  if (uniform) {
+    for (int i = threadIdx.x; i < 3 * kSahBins; i += blockDim.x) {
+      const int a = i / kSahBins, b = i % kSahBins;
+      B.cnt[a][b] = 0;
+      for (int k = 0; k < 3; k++) { B.lo[a][b][k] = float_to_ordered(1e37f); B.hi[a][b][k] = float_to_ordered(-1e37f); }
+    }
+    __syncthreads();
+  }
+  const int ti = uniform ? tFirst : (p < n ? sah_task_of(tasks, nTasks, p) : -1);
+  if (p < n && ti >= 0 && tasks[ti].count > leafSize) {
+    const SahTask t = tasks[ti];
+    SahBins* dst = uniform ? &B : &bins[ti];
+    const int f = order[p];
+    const float l[3] = { lo[3 * f], lo[3 * f + 1], lo[3 * f + 2] }, h[3] = { hi[3 * f], hi[3 * f + 1], hi[3 * f + 2] };
+    for (int a = 0; a < 3; a++) {
+      const int b = sah_bin((l[a] + h[a]) * 0.5f, t.cbLo[a], sah_scale(t.cbLo[a], t.cbHi[a]));
+      atomicAdd(&dst->cnt[a][b], 1);
+      for (int k = 0; k < 3; k++) { atomicMin(&dst->lo[a][b][k], float_to_ordered(l[k])); atomicMax(&dst->hi[a][b][k], float_to_ordered(h[k])); }
+    }
+  }
+  if (uniform) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * kSahBins; i += blockDim.x) {
+      const int a = i / kSahBins, b = i % kSahBins;
+      if (B.cnt[a][b] == 0) continue;
+      atomicAdd(&bins[tFirst].cnt[a][b], B.cnt[a][b]);
+      for (int k = 0; k < 3; k++) { atomicMin(&bins[tFirst].lo[a][b][k], B.lo[a][b][k]); atomicMax(&bins[tFirst].hi[a][b][k], B.hi[a][b][k]); }
+    }
+  }
+}
+__global__ void k_sahw_choose(const SahTask* __restrict__ tasks, int nTasks, int leafSize, int useSah, const SahBins* __restrict__ bins,
+                              SahSplit* __restrict__ splits) {
+  const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ti >= nTasks) return;
+  const SahTask t = tasks[ti];
+  SahSplit sp; sp.axis = -1; sp.bin = 0; sp.nLeft = (t.count + 1) / 2;
+  if (useSah && t.count > leafSize) sp = sah_choose(bins[ti], mk3(t.cbLo[0], t.cbLo[1], t.cbLo[2]), mk3(t.cbHi[0], t.cbHi[1], t.cbHi[2]), t.count);
+  splits[ti] = sp;
+}
+__device__ __forceinline__ bool sahw_left(const SahTask& t, const SahSplit& sp, int p, int f, const float* __restrict__ lo, const float* __restrict__ hi) {
+  if (sp.axis < 0) return (p - t.first) < sp.nLeft;
+  const float c = (lo[3 * f + sp.axis] + hi[3 * f + sp.axis]) * 0.5f;
+  return sah_bin(c, t.cbLo[sp.axis], sah_scale(t.cbLo[sp.axis], t.cbHi[sp.axis])) < sp.bin;
+}
+__global__ void k_sahw_side(int n, const SahTask* __restrict__ tasks, int nTasks, const SahSplit* __restrict__ splits,
+                            const float* __restrict__ lo, const float* __restrict__ hi, const int* __restrict__ order, int* __restrict__ leftFlag) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int ti = sah_task_of(tasks, nTasks, p);
+  leftFlag[p] = (ti >= 0 && sahw_left(tasks[ti], splits[ti], p, order[p], lo, hi)) ? 1 : 0;
+}
+__global__ void k_sahw_scatter(int n, const SahTask* __restrict__ tasks, int nTasks, const SahSplit* __restrict__ splits,
+                               const float* __restrict__ lo, const float* __restrict__ hi, const int* __restrict__ order,
+                               const int* __restrict__ leftFlag, const int* __restrict__ leftScan, int* __restrict__ tmp, uint32_t* childCb) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ti = p < n ? sah_task_of(tasks, nTasks, p) : -1;
+  const bool valid = ti >= 0;
+  bool left = false;
+  float c[3] = { 0.f, 0.f, 0.f };
+  if (valid) {
+    const SahTask t = tasks[ti];
+    const SahSplit sp = splits[ti];
+    const int f = order[p];
+    left = leftFlag[p] != 0;
+    const int leftRank = leftScan[p] - leftScan[t.first];             // "goes left" among the positions before p in this range
+    tmp[left ? t.first + leftRank : t.first + sp.nLeft + (p - t.first - leftRank)] = f;
+    for (int a = 0; a < 3; a++) c[a] = (lo[3 * f + a] + hi[3 * f + a]) * 0.5f;
+  }
+  // centroid boxes of the two halves: one wave = one node almost always, so reduce in the wave and let one lane
+  // do the 12 atomics (64 lanes on 12 addresses would serialise in the memory system)
+  const int t0 = __builtin_amdgcn_readfirstlane(ti);
+  if (__ballot(ti != t0) == 0ull) {
+    if (t0 < 0) return;
+    float r[12];
+    for (int s2 = 0; s2 < 2; s2++)
+      for (int a = 0; a < 3; a++) {
+        const bool mine = valid && (left == (s2 == 0));
+        r[6 * s2 + a] = wave_min(mine ? c[a] : 1e37f); r[6 * s2 + 3 + a] = wave_max(mine ? c[a] : -1e37f);
+      }
+    if ((threadIdx.x & 63) == 0) {
+      uint32_t* cb = childCb + 12 * (size_t)t0;
+      for (int s2 = 0; s2 < 2; s2++) for (int a = 0; a < 3; a++) { atomicMin(&cb[6 * s2 + a], float_to_ordered(r[6 * s2 + a])); atomicMax(&cb[6 * s2 + 3 + a], float_to_ordered(r[6 * s2 + 3 + a])); }
+    }
+  } else if (valid) {
+    uint32_t* cb = childCb + 12 * (size_t)ti + (left ? 0 : 6);
+    for (int a = 0; a < 3; a++) { atomicMin(&cb[a], float_to_ordered(c[a])); atomicMax(&cb[3 + a], float_to_ordered(c[a])); }
+  }
+}
+__global__ void k_sahw_commit(int n, const SahTask* __restrict__ tasks, int nTasks, const SahSplit* __restrict__ splits,
+                              const uint32_t* __restrict__ childCb, const int* __restrict__ tmp, int* __restrict__ order,
+                              int* __restrict__ first, int* __restrict__ last, SahTask* __restrict__ children) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && sah_task_of(tasks, nTasks, p) >= 0) order[p] = tmp[p];
+  if (p < nTasks) {
+    const SahTask t = tasks[p];
+    const SahSplit sp = splits[p];
+    first[t.node] = t.first; last[t.node] = t.first + t.count - 1;
+    for (int s2 = 0; s2 < 2; s2++) {
+      SahTask ch; ch.node = -1; ch.first = t.first + (s2 ? sp.nLeft : 0); ch.count = s2 ? t.count - sp.nLeft : sp.nLeft;
+      for (int a = 0; a < 3; a++) { ch.cbLo[a] = ordered_to_float(childCb[12 * (size_t)p + 6 * s2 + a]); ch.cbHi[a] = ordered_to_float(childCb[12 * (size_t)p + 6 * s2 + 3 + a]); }
+      children[2 * (size_t)p + s2] = ch;
+    }
+  }
+}
+
 __global__ void k_sah_flags(int nChildren, const SahTask* __restrict__ children, int* __restrict__ flags) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < nChildren) flags[c] = children[c].count >= 2 ? 1 : 0;
@@ -213,7 +344,7 @@ __global__ void k_sah_finalize(int nChildren, const SahTask* __restrict__ tasks,
   const int node = tasks[c >> 1].node;
   SahTask ch = children[c];
   int ref;
-  if (flags[c]) { ref = nextBase + offs[c]; ch.node = ref; parentI[ref] = node; nextTasks[offs[c]] = ch; }
+  if (flags[c]) { ref = nextBase + offs[c]; ch.node = ref; parentI[ref] = node; nextTasks[offs[c]] = ch; atomicMax(nextCount + 1, ch.count); }
   else { ref = ~ch.first; parentL[ch.first] = node; }
   if (c & 1) right[node] = ref; else left[node] = ref;
   if (c == nChildren - 1) *nextCount = offs[c] + flags[c];
@@ -338,7 +469,10 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
   uint64_t *keys = nullptr, *keysSorted = nullptr;
   int *left = nullptr, *right = nullptr, *first = nullptr, *last = nullptr, *parentI = nullptr, *parentL = nullptr, *kept = nullptr, *newIndex = nullptr, *opened = nullptr;
   unsigned int* arrivals = nullptr; SceneBox* box = nullptr; int* dDepth = nullptr; void* tmp = nullptr;
-  int *order = nullptr, *orderTmp = nullptr, *sahFlags = nullptr, *sahOffs = nullptr, *sahNext = nullptr;
+  int *order = nullptr, *orderTmp = nullptr, *sahFlags = nullptr, *sahOffs = nullptr, *sahNext = nullptr, *sahLeft = nullptr, *sahLeftScan = nullptr;
+  SahBins* sahBins = nullptr; SahSplit* sahSplits = nullptr; uint32_t* sahChildCb = nullptr;
+  constexpr int kWideTasks = 1024;      // the per-triangle form handles levels with at most this many nodes ...
+  constexpr int kWideCount = 2048;      // ... while some node still holds more triangles than this
   SahTask *tasksA = nullptr, *tasksB = nullptr, *sahChildren = nullptr;
   size_t tmpSah = 0;
   size_t tmpSort = 0, tmpScan = 0, tmpBytes = 0;
@@ -358,9 +492,11 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
   if (ni > 0) LB_CHECK(rocprim::exclusive_scan(nullptr, tmpScan, kept, newIndex, 0, (size_t)ni, rocprim::plus<int>(), stream));
   if (builder == 1 && n > leafSize) {
     LB_CHECK(dmalloc(&order, (size_t)n)); LB_CHECK(dmalloc(&orderTmp, (size_t)n));
-    LB_CHECK(dmalloc(&sahFlags, (size_t)n + 2)); LB_CHECK(dmalloc(&sahOffs, (size_t)n + 2)); LB_CHECK(dmalloc(&sahNext, 1));
+    LB_CHECK(dmalloc(&sahFlags, (size_t)n + 2)); LB_CHECK(dmalloc(&sahOffs, (size_t)n + 2)); LB_CHECK(dmalloc(&sahNext, 2));
+    LB_CHECK(dmalloc(&sahLeft, (size_t)n + 1)); LB_CHECK(dmalloc(&sahLeftScan, (size_t)n + 1));
+    LB_CHECK(dmalloc(&sahBins, (size_t)kWideTasks)); LB_CHECK(dmalloc(&sahSplits, (size_t)kWideTasks)); LB_CHECK(dmalloc(&sahChildCb, 12 * (size_t)kWideTasks));
     LB_CHECK(dmalloc(&tasksA, (size_t)n / 2 + 2)); LB_CHECK(dmalloc(&tasksB, (size_t)n / 2 + 2)); LB_CHECK(dmalloc(&sahChildren, (size_t)n + 2));
-    LB_CHECK(rocprim::exclusive_scan(nullptr, tmpSah, sahFlags, sahOffs, 0, (size_t)n + 2, rocprim::plus<int>(), stream));
+    LB_CHECK(rocprim::exclusive_scan(nullptr, tmpSah, sahFlags, sahOffs, 0, (size_t)n + 2, rocprim::plus<int>(), stream));   // >= any scan below
     if (tmpSah > tmpScan) tmpScan = tmpSah;
   }
   tmpBytes = tmpSort > tmpScan ? tmpSort : tmpScan;
@@ -375,20 +511,32 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
     // binned-SAH topology over the Morton order, one launch per level (pt_lbvh.h); the final order replaces the keys
     k_sah_init<<<grid_for(n), kBlock, 0, stream>>>(n, keysSorted, order, tasksA, box);
     LB_CHECK(hipMemsetAsync(parentI, 0xff, sizeof(int) * (size_t)ni, stream));          // root: parent -1
-    int nActive = 1, idBase = 0, level = 0;
+    int nActive = 1, idBase = 0, level = 0, maxCount = n;
     SahTask *cur = tasksA, *nxt = tasksB;
     while (nActive > 0) {
       const int nChildren = 2 * nActive;
-      k_sah_level<<<nActive, kSahBlock, 0, stream>>>(cur, leafSize, level < kSahLevels ? 1 : 0, lo, hi, order, orderTmp, first, last, sahChildren);
+      const int useSah = level < kSahLevels ? 1 : 0;
+      LB_CHECK(hipMemsetAsync(sahNext, 0, 2 * sizeof(int), stream));
+      if (nActive <= kWideTasks && maxCount > kWideCount) {
+        k_sahw_clear<<<grid_for(nActive * 3 * kSahBins), kBlock, 0, stream>>>(nActive, sahBins, sahChildCb);
+        if (useSah) k_sahw_bin<<<grid_for(n), kBlock, 0, stream>>>(n, cur, nActive, leafSize, lo, hi, order, sahBins);
+        k_sahw_choose<<<grid_for(nActive), kBlock, 0, stream>>>(cur, nActive, leafSize, useSah, sahBins, sahSplits);
+        k_sahw_side<<<grid_for(n), kBlock, 0, stream>>>(n, cur, nActive, sahSplits, lo, hi, order, sahLeft);
+        size_t tb2 = tmpBytes;
+        LB_CHECK(rocprim::exclusive_scan(tmp, tb2, sahLeft, sahLeftScan, 0, (size_t)n, rocprim::plus<int>(), stream));
+        k_sahw_scatter<<<grid_for(n), kBlock, 0, stream>>>(n, cur, nActive, sahSplits, lo, hi, order, sahLeft, sahLeftScan, orderTmp, sahChildCb);
+        k_sahw_commit<<<grid_for(n > nActive ? n : nActive), kBlock, 0, stream>>>(n, cur, nActive, sahSplits, sahChildCb, orderTmp, order, first, last, sahChildren);
+      } else
+      k_sah_level<<<nActive, kSahBlock, 0, stream>>>(cur, leafSize, useSah, lo, hi, order, orderTmp, first, last, sahChildren);
       k_sah_flags<<<grid_for(nChildren), kBlock, 0, stream>>>(nChildren, sahChildren, sahFlags);
       size_t tb = tmpBytes;
       LB_CHECK(rocprim::exclusive_scan(tmp, tb, sahFlags, sahOffs, 0, (size_t)nChildren, rocprim::plus<int>(), stream));
       k_sah_finalize<<<grid_for(nChildren), kBlock, 0, stream>>>(nChildren, cur, sahChildren, sahFlags, sahOffs, idBase + nActive,
                                                                 left, right, parentI, parentL, nxt, sahNext);
-      int nextActive = 0;
-      LB_CHECK(hipMemcpyAsync(&nextActive, sahNext, sizeof(int), hipMemcpyDeviceToHost, stream));
+      int nextInfo[2] = { 0, 0 };
+      LB_CHECK(hipMemcpyAsync(nextInfo, sahNext, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
       LB_CHECK(hipStreamSynchronize(stream));
-      idBase += nActive; nActive = nextActive; level++;
+      idBase += nActive; nActive = nextInfo[0]; maxCount = nextInfo[1]; level++;
       SahTask* sw = cur; cur = nxt; nxt = sw;
     }
     k_order_keys<<<grid_for(n), kBlock, 0, stream>>>(n, order, keysSorted);
@@ -425,7 +573,8 @@ done:
   for (void* p : { (void*)lo, (void*)hi, (void*)leafLo, (void*)leafHi, (void*)ilo, (void*)ihi, (void*)keys, (void*)keysSorted,
                    (void*)left, (void*)right, (void*)first, (void*)last, (void*)parentI, (void*)parentL, (void*)kept, (void*)newIndex,
                    (void*)arrivals, (void*)box, (void*)dDepth, (void*)opened, tmp, (void*)order, (void*)orderTmp, (void*)sahFlags,
-                   (void*)sahOffs, (void*)sahNext, (void*)tasksA, (void*)tasksB, (void*)sahChildren })
+                   (void*)sahOffs, (void*)sahNext, (void*)tasksA, (void*)tasksB, (void*)sahChildren, (void*)sahLeft, (void*)sahLeftScan,
+                   (void*)sahBins, (void*)sahSplits, (void*)sahChildCb })
     if (p) (void)hipFree(p);
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
