@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
   {
     const int first = SHARED ? threadIdx.x : lane, step = SHARED ? kBlockThreads : 64;
     for (int s = first; s < nUse; s += step) {
-      i4 ctl; ctl.x = 0; ctl.y = 0; ctl.z = 0; ctl.w = M_NEW_PIXEL;
+      i4 ctl; ctl.x = -1; ctl.y = 0; ctl.z = 0; ctl.w = M_NEW_PIXEL;     // item -1: whatever sample comes first is "new" (rows get written)
       cold[s].ctl = ctl;
       W.stack[s][0] = 0;
       W.queue[Q_GEN][s] = (unsigned short)s;
@@ -349,13 +349,18 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     bool shadowIn = false;                       // this visit started with a shadow ray coming back
-    v4 thrIn = mk4(0.f, 0.f, 0.f, 0.f), radIn = thrIn;
+    // which rows this visit has to write back.  Throughput changes with a bounce (depth) or a new sample (item) only;
+    // radiance and the texture colour are compared around on_result (short live ranges instead of two rows of registers
+    // held across the whole batch)
+    int depthIn = 0, itemIn = 0;
+    bool radDirty = false, texDirty = false;
     if (have) {
       const SlotCold* cs = cold + slot;
       const int fl = W.stack[slot][0];
       const bool shadow = (fl & kShadowRay) != 0, hitValid = (fl & kHitValid) != 0;
       const i4 ctl = slot_load(&cs->ctl);
-      thrIn = slot_load(&cs->thr); radIn = slot_load(&cs->rad);
+      const v4 thrIn = slot_load(&cs->thr), radIn = slot_load(&cs->rad);
+      depthIn = ctl.y; itemIn = ctl.x;
       v4 wh = mk4(0.f, 0.f, 0.f, 0.f);
       v4 wn = mk4(0.f, 0.f, 1.f, 0.f), wv = mk4(0.f, 0.f, 1.f, 0.f), wp = mk4(0.f, 0.f, 0.f, 0.f);
       if (hitValid) wh = slot_load(&cs->hit);
@@ -399,7 +404,10 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       }
       if (run) {
         if (ps.mode == M_RESULT) {
+          const v3 r0 = ps.rad, c0 = ps.cdlin;
           on_result<CNT>(sc, ps, res, ct);
+          radDirty = radDirty || f2i(r0.x) != f2i(ps.rad.x) || f2i(r0.y) != f2i(ps.rad.y) || f2i(r0.z) != f2i(ps.rad.z);
+          texDirty = texDirty || f2i(c0.x) != f2i(ps.cdlin.x) || f2i(c0.y) != f2i(ps.cdlin.y) || f2i(c0.z) != f2i(ps.cdlin.z);
         } else if (ps.mode == M_LIGHTS) {
           on_lights<CNT, FAST>(sc, ps, ct);
         } else {  // M_NEW_PIXEL: next (pixel, sample) work item
@@ -418,11 +426,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       i4 ctl; ctl.x = ps.item; ctl.y = ps.depth; ctl.z = (int)ps.seed; ctl.w = ps.mode | (ps.light << 3);
       slot_store(&cw->ctl, ctl);
       // throughput and radiance rows: only when their bits changed (a shadow ray leaves thr alone, a glass bounce leaves rad alone)
-      const v4 thrOut = mk4(ps.thr.x, ps.thr.y, ps.thr.z, ps.cdlin.y), radOut = mk4(ps.rad.x, ps.rad.y, ps.rad.z, ps.cdlin.z);
-      if (f2i(thrOut.x) != f2i(thrIn.x) || f2i(thrOut.y) != f2i(thrIn.y) || f2i(thrOut.z) != f2i(thrIn.z) || f2i(thrOut.w) != f2i(thrIn.w))
-        slot_store(&cw->thr, thrOut);
-      if (f2i(radOut.x) != f2i(radIn.x) || f2i(radOut.y) != f2i(radIn.y) || f2i(radOut.z) != f2i(radIn.z) || f2i(radOut.w) != f2i(radIn.w))
-        slot_store(&cw->rad, radOut);
+      const bool newPath = ps.item != itemIn || ps.depth != depthIn;      // bounce or new sample
+      if (newPath || texDirty) slot_store(&cw->thr, mk4(ps.thr.x, ps.thr.y, ps.thr.z, ps.cdlin.y));
+      if (ps.item != itemIn || radDirty || texDirty) slot_store(&cw->rad, mk4(ps.rad.x, ps.rad.y, ps.rad.z, ps.cdlin.z));
       if (ps.mode == M_TRACE) {
         // new ray: analytic primitives + traversal set-up happen here, on the full batch
         Trav tv;
