@@ -87,9 +87,9 @@ PT_HD v3 cosine_sample_hemisphere(float u1, float u2) {
 }
 
 // disney.h:9-30
-PT_HD_BRDF void disney_sample(uint32_t& seed, const DevMaterial& m, v3 N, v3 V, v3& L, v3& H) {
+// onb = make_onb(N): disney.h builds it in disneySample and again in disneyEval; the caller builds it once
+PT_HD_BRDF void disney_sample(uint32_t& seed, const DevMaterial& m, const Onb& onb, v3 V, v3& L, v3& H) {
   typedef ShadeMath<false> SM;         // directions are part of the path: always exact
-  Onb onb = make_onb(N);
   if (rnd(seed) < m.diffuseRatio) {
     float u1 = rnd(seed); float u2 = rnd(seed);
     v3 l = cosine_sample_hemisphere(u1, u2);
@@ -128,9 +128,9 @@ PT_HD_BRDF float disney_pdf(const DevMaterial& m, v3 N, v3 L, v3 H) {
 // disney.h:48-91
 // Cdlin/Cspec0/Csheen: the material's constants, or the per-hit ones of a textured material
 template <bool FAST = false>
-PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 Cdlin, v3 Cspec0, v3 Csheen, v3 N, v3 L, v3 V, v3 H) {
+PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 Cdlin, v3 Cspec0, v3 Csheen, const Onb& onb, v3 L, v3 V, v3 H) {
   typedef ShadeMath<FAST> SM;
-  Onb onb = make_onb(N);
+  const v3 N = onb.normal;
   float NdotL = dot(N, L), NdotV = dot(N, V), NdotH = dot(N, H), LdotH = dot(L, H);
   const v3 one = mk3(1.f, 1.f, 1.f);
 

@@ -447,7 +447,7 @@ PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
     } else {
       const float r1 = rnd(ps.seed); const float r2 = rnd(ps.seed);
       pointOnLight = (lt->position + lt->u * r1) + lt->v * r2;
-      normalOnLight = normalize(lt->normal);
+      normalOnLight = lt->normal;            // normalize(light.normal) (Material.cu:181), taken once at upload (pt_upload.h)
     }
     L = pointOnLight - ps.o;
     lightDst = length(L);
@@ -461,8 +461,9 @@ PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
     }
     ps.light++;
   }
+  const Onb onb = make_onb(ps.N);
   if (choice == 0) {
-    disney_sample(ps.seed, m, ps.N, ps.V, L, H);
+    disney_sample(ps.seed, m, onb, ps.V, L, H);
     if (dot(ps.N, L) > 0.0f && dot(ps.N, ps.V) > 0.0f) choice = 2;
   }
   if (choice == 0) { end_sample(ps); return; }
@@ -473,7 +474,7 @@ PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
     disney_color_constants(Cdlin, m.specular, m.specularTint, m.sheenTint, m.metallic, Cspec0, Csheen);
   }
   const float pdf = disney_pdf<FAST>(m, ps.N, L, H);
-  const v3 brdf = disney_eval<FAST>(m, Cdlin, Cspec0, Csheen, ps.N, L, ps.V, H);
+  const v3 brdf = disney_eval<FAST>(m, Cdlin, Cspec0, Csheen, onb, L, ps.V, H);
 
   if (choice == 1) {
     if (lightPdf > 0 && pdf > 0) {

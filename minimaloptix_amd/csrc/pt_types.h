@@ -65,7 +65,7 @@ static_assert(sizeof(DevSphere) == 16, "DevSphere must be 16 bytes");
 
 struct alignas(16) DevLight {  // LightParams (Structures.h:70)
   v3 position; float area;
-  v3 normal;   float radius;
+  v3 normal;   float radius;   // quad lights: normalize(LightParams.normal), taken at upload (pt_upload.h)
   v3 emission; int shape;
   v3 u; int pad0;
   v3 v; int pad1;

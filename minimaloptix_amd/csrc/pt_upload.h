@@ -58,7 +58,10 @@ inline DevSphere make_dev_sphere(const moptix_sphere_params& s) {
 inline DevLight make_dev_light(const moptix_light_params& l) {
   DevLight d;
   memset(&d, 0, sizeof(d));
-  d.position = to_v3(l.position); d.normal = to_v3(l.normal); d.emission = to_v3(l.emission);
+  d.position = to_v3(l.position); d.emission = to_v3(l.emission);
+  // Material.cu:181 normalizes the quad light's normal at every use; same correctly rounded operations, once (a sphere
+  // light's normal is recomputed per sample from the sampled point and never read from here)
+  d.normal = l.shape == MOPTIX_LIGHT_QUAD ? normalize(to_v3(l.normal)) : to_v3(l.normal);
   d.u = to_v3(l.u); d.v = to_v3(l.v); d.area = l.area; d.radius = l.radius; d.shape = l.shape;
   return d;
 }
