@@ -284,3 +284,20 @@ def test_slots_in_use_is_a_scheduling_knob_only(gpu_ctx):
             assert np.array_equal(got, ref), n
     finally:
         gpu_ctx.set_option("slots_in_use", -1)
+
+
+def test_analytic_scenes_through_the_queue_kernel(gpu_ctx):
+    """"NoAccel" scenes (spheres / quads only) normally run on the per-lane kernel; option analytic_queue = 1 sends
+    them through the queue kernel, where a ray is finished by the brute-force lists at set-up: same bits."""
+    hs = M.HostScene("random_spheres", 160, 90, iarg=97)
+    seeds = M.launch_seeds(3)
+    gpu_ctx.load(hs)
+    ref, _ = _render(gpu_ctx, seeds)
+    try:
+        gpu_ctx.set_option("analytic_queue", 1)
+        got, _ = _render(gpu_ctx, seeds)
+    finally:
+        gpu_ctx.set_option("analytic_queue", 0)
+    assert np.array_equal(got, ref)
+    o, _ = oracle_scene(hs).render(seeds)
+    assert rmse(got / 3, o / 3) <= RMSE_TIGHT
