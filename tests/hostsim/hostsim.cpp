@@ -13,6 +13,7 @@
 #include <vector>
 #include <omp.h>
 #include "../../minimaloptix_amd/csrc/pt_path.h"
+#include "../../minimaloptix_amd/csrc/pt_packet.h"
 #include "../../minimaloptix_amd/csrc/pt_lbvh.h"
 #include "../../minimaloptix_amd/csrc/pt_upload.h"
 
@@ -127,6 +128,7 @@ static void build_sah_topology(const std::vector<v3>& lo, const std::vector<v3>&
   }
 }
 
+static int g_packet = 0;      // 1 = the per-bounce state machine of pt_packet.h (kernel variant 4) instead of the per-ray one
 static int g_builder = 1;     // 0 = Morton radix tree (Karras), 1 = binned SAH over the Morton order (device default)
 
 static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
@@ -299,6 +301,7 @@ static void make_scene(const hostsim_scene& s, int leafSize, HostScene& hs) {
 extern "C" {
 
 void hostsim_set_builder(int builder) { g_builder = builder; }
+void hostsim_set_packet(int packet) { g_packet = packet; }
 
 int hostsim_build_bvh(const hostsim_scene* s, int leafSize, hostsim_bvh_out* out) {
   HostBVH b; build_lbvh(*s, leafSize, b);
@@ -332,16 +335,36 @@ int hostsim_render_timed(const hostsim_scene* s, int leafSize, const int32_t* se
       ps.pixel = pix; ps.item = 0;
       v3 acc = mk3(accum[3 * pix], accum[3 * pix + 1], accum[3 * pix + 2]);
       int sIdx = 0;
+      Packet pk; packet_primary(pk);
+      v3 att[kPacketShadows] = { mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f) };
       if (nSeeds > 0) begin_sample<true>(sc, ps, seeds[0], ct); else ps.mode = M_DONE;
       while (ps.mode != M_DONE) {
         if (ps.mode == M_NEW_SAMPLE) {            // Camera.cu:41, one launch after the other
           acc = acc + ps.accum;
           if (++sIdx >= nSeeds) break;
           begin_sample<true>(sc, ps, seeds[sIdx], ct);
+          packet_primary(pk);
+        } else if (ps.mode == M_TRACE && g_packet) {
+          // the packet's rays, each on its own: shadow rays in light order, then the continuation
+          for (int i = 0; i < pk.nShadow; i++) {
+            PathState r = ps; Trav ts; memset(&ts, 0, sizeof(ts));
+            r.d = pk.sd[i]; r.tmin = sc.epsT; r.tmax = pk.stmax[i]; r.kind = RK_SHADOW;
+            trav_begin<true>(sc, r, ts, ct);
+            while (ts.node != kTravDone) trav_step<true>(sc, r, ts, st, ct);
+            att[i] = ts.att;
+          }
+          if (pk.hasBounce) {
+            ps.kind = RK_RADIANCE;
+            trav_begin<true>(sc, ps, tv, ct);
+            while (tv.node != kTravDone) trav_step<true>(sc, ps, tv, st, ct);
+          }
+          ps.mode = M_RESULT;
         } else if (ps.mode == M_TRACE) {
           trav_begin<true>(sc, ps, tv, ct);
           while (tv.node != kTravDone) trav_step<true>(sc, ps, tv, st, ct);
           ps.mode = M_RESULT;
+        } else if (ps.mode == M_RESULT && g_packet) {
+          on_result_packet<true>(sc, ps, pk, tv, att, ct);
         } else if (ps.mode == M_RESULT) {
           on_result<true>(sc, ps, tv, ct);
         } else if (ps.mode == M_LIGHTS) {
