@@ -85,6 +85,10 @@ int queuekernel_slots();
 size_t queuekernel_cold_bytes(int nBlocks);
 size_t queuekernel_overflow_ints(int nBlocks, int ovfDepth);
 hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool shared, bool counted, bool fastShading);
+int packetkernel_lds_stack_entries();
+size_t packetkernel_cold_bytes(int nBlocks);
+size_t packetkernel_overflow_ints(int nBlocks, int ovfDepth);
+hipError_t launch_packetkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading);
 hipError_t launch_debug_trace(hipStream_t stream, const SceneView& sc, const float* dRays, int n, float* dT, int* dPrim, int* stackOverflow);
 hipError_t launch_resolve_rgb8(hipStream_t stream, float* accum, int width, int height, float nAccumulation, int clearBuffer, uint8_t* dOut);
 

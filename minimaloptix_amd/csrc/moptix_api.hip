@@ -210,11 +210,22 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   // scenes without triangles ("NoAccel") run on the per-lane kernel.  Option "analytic_queue" = 1 sends them through the
   // queue kernel instead (every ray is finished by the brute-force lists at set-up, inside a full shading batch, and the
   // slots cycle through the batches); measured: random_spheres 500 92.3 -> 88.3 ms, cornell_quads 16.5 -> 22.9 ms, so off
-  const bool useQueue = (c->optVariant == 2 || c->optVariant == 3) && (hasTris || c->optAnalyticQueue != 0);
+  // variant 4 (packetkernel.hip, one shading visit per bounce): triangle scenes with at most three lights and no Disney
+  // material on an analytic primitive; anything else runs on variant 3
+  const bool usePacket = c->optVariant == 4 && hasTris && a.scene.nLights <= 3 && !a.scene.anyDisneyAnalytic;
+  const bool useQueue = !usePacket && (c->optVariant >= 2) && (hasTris || c->optAnalyticQueue != 0);
   a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;
   a.slotsInUse = c->optSlotsInUse;     // resolved per pass below when -1
   a.watchdogTicks = (unsigned long long)c->optWatchdogMs * 100000ull;      // s_memrealtime counts at 100 MHz
-  if (useQueue) {
+  if (usePacket) {
+    a.ovfDepth = std::max(0, c->bvh.stackBound - packetkernel_lds_stack_entries() + 1);
+    if (a.ovfDepth > 0) {
+      HIPCHK(c, c->dOverflow.ensure(packetkernel_overflow_ints(nBlocks, a.ovfDepth)), "alloc stack overflow area");
+      a.stackOverflow = c->dOverflow.p;
+    }
+    HIPCHK(c, c->dPoolCold.ensure(packetkernel_cold_bytes(nBlocks)), "alloc path pool");
+    a.poolCold = c->dPoolCold.p;
+  } else if (useQueue) {
     a.ovfDepth = std::max(0, c->bvh.stackBound - queuekernel_lds_stack_entries() + 1);
     if (a.ovfDepth > 0) {
       HIPCHK(c, c->dOverflow.ensure(queuekernel_overflow_ints(nBlocks, a.ovfDepth)), "alloc stack overflow area");
@@ -237,7 +248,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   HIPCHK(c, c->dSampleBuf.ensure((size_t)perPass * a.nItems * 3), "alloc per-sample buffer");
   a.sampleBuf = c->dSampleBuf.p;
   HIPCHK(c, c->dWork.ensure(2), "alloc work counter");   // [0] work counter, [1] watchdog flag
-  a.tileMajor = useQueue ? c->optTileMajor : 0;
+  a.tileMajor = (useQueue || usePacket) ? c->optTileMajor : 0;
   a.tileOrder = nullptr; a.tileCost = nullptr;
   a.unitShift = a.tileMajor == 3 ? 0 : 6;
   const long long historyUnits = (localTiles * 64) >> a.unitShift;
@@ -280,7 +291,8 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
                                                (size_t)historyUnits, 0, 32, c->stream), "sort tiles");
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
-    if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, c->optVariant == 3, counted, c->optFastShading != 0), "launch queue megakernel");
+    if (usePacket) HIPCHK(c, launch_packetkernel(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch packet megakernel");
+    else if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, c->optVariant != 2, counted, c->optFastShading != 0), "launch queue megakernel");
     else if (usePool) HIPCHK(c, launch_poolkernel(c->stream, a, nBlocks, c->optPoolSlots, counted), "launch pool megakernel");
     else HIPCHK(c, launch_megakernel(c->stream, a, nBlocks, counted), "launch megakernel");
     HIPCHK(c, hipEventRecord(c->ev1, c->stream), "event");
@@ -585,7 +597,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   if (!strcmp(name, "exit_threshold")) { if (value < 0 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "exit_threshold in [0,64]"); c->optExitThreshold = value; }
   else if (!strcmp(name, "leaf_size")) { if (value < 1 || value > kMaxLeaf) return fail(c, MOPTIX_ERR_INVALID, "leaf_size in [1,8]"); if (value != c->optLeafSize) c->accelBuilt = false; c->optLeafSize = value; }
   else if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) return fail(c, MOPTIX_ERR_INVALID, "blocks_per_cu in [1,8]"); c->optBlocksPerCU = value; }
-  else if (!strcmp(name, "kernel_variant")) { if (value < 0 || value > 3) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {0,1,2,3}"); c->optVariant = value; }
+  else if (!strcmp(name, "kernel_variant")) { if (value < 0 || value > 4) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {0,1,2,3,4}"); c->optVariant = value; }
   else if (!strcmp(name, "pool_slots")) { if (value != 128 && value != 192 && value != 256) return fail(c, MOPTIX_ERR_INVALID, "pool_slots in {128,192,256}"); c->optPoolSlots = value; }
   else if (!strcmp(name, "sample_buffer_mb")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "sample_buffer_mb >= 1"); c->optSampleBufMB = value; }
   else if (!strcmp(name, "leaf_threshold")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "leaf_threshold in [1,64]"); c->optLeafThreshold = value; }

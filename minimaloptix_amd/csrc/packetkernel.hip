@@ -1,0 +1,668 @@
+// packetkernel.hip -- megakernel variant 4: the scheduler of variant 3 (queuekernel.hip: path slots with their traversal
+// state in LDS, node / leaf / shade / gen queues shared by the workgroup, lanes as workers) around the PER-BOUNCE state
+// machine of pt_packet.h.
+//
+// Variant 3 gives every ray its own shading visit: a Disney hit with three facing lights is four trips through the
+// shade queue, four slot-record round trips and four traversal set-ups, one after the other.  Here a visit does all of a
+// hit's work that does not depend on a trace (every light draw, the facing tests, disneyPdf / disneyEval per light, the
+// BRDF sample, the seed fork) and leaves a PACKET: up to three shadow rays and the continuation ray, all from the hit
+// point.  The slot then traces the packet's rays one after the other WITHOUT going back to shading: when a ray ends and
+// another one is pending, the next leaf pass loads that ray (16 bytes of the slot record) and restarts the slot at the
+// root.  The visit that follows folds the shadow results into the radiance in light order and shades the continuation's
+// hit.  Same random draws, same decisions, same floating-point operations on the path's values as variants 0-3 (the
+// images are bit-identical); a path of depth k is a chain of k visits instead of up to 4k.
+//
+// Limits (moptix_api.hip falls back to variant 3 otherwise): at most kPacketShadows lights, no Disney material on an
+// analytic primitive (shadow rays then need the brute-force lists at every ray start).
+#include <hip/hip_runtime.h>
+
+#include "megakernel.h"
+#include "pt_path.h"
+#include "pt_packet.h"
+
+namespace pt {
+
+namespace {
+
+constexpr int kBlockThreads = 256;
+constexpr int kWaves = kBlockThreads / 64;
+#ifndef PT_KP
+#define PT_KP 128
+#endif
+#ifndef PT_STACKN
+#define PT_STACKN 11
+#endif
+#ifndef PT_WAVES_PER_SIMD
+#define PT_WAVES_PER_SIMD 3
+#endif
+constexpr int kP = PT_KP;               // slots per wave
+constexpr int kStackN = PT_STACKN;      // LDS stack entries per slot; deeper levels spill to HBM
+constexpr int kWavesPerSimd = PT_WAVES_PER_SIMD;   // occupancy target: 3 workgroups per CU (VGPR <= 168, LDS <= 53 KB)
+constexpr int ring_capacity(int n) { int c = 1; while (c < n) c <<= 1; return c; }
+
+// pool-wide queues first (they index PoolLds::queue); Q_NODE / Q_LEAF are per-wave rings (WavePriv)
+enum { Q_SHADE = 0, Q_GEN = 1, kNumQ = 2, Q_NODE = 2, Q_LEAF = 3, DEST_DONE = 4, DEST_NONE = -1 };
+
+// Path-slot record in HBM, private to the pool: two 128-byte lines of 16-byte rows.
+//   line 0, the shading visit's rows: ctl thr rad hit bsc pend[3]
+//   line 1, the traversal's rows:     ray[3] (the packet's rays after the first, in trace order) att[3] (shadow
+//                                     attenuations, only once a glass surface was crossed)
+// A shading visit reads line 0 (the pend rows only for the packet's shadow rays) and writes it back; a ray switch reads
+// one ray row; the leaf pass reads / writes hit (continuation) or att (shadow ray, tinted only).
+struct alignas(16) i4 { int x, y, z, w; };
+struct alignas(128) SlotCold {
+  i4 ctl;       // item, depth, seed, mode | nShadow << 3 | hasBounce << 5 | hasScale << 6
+  v4 thr;       // throughput (of the hit the packet left from: the shadow results are folded with it)
+  v4 rad;       // radiance so far
+  v4 hit;       // continuation ray: bestTri, bestPrim (int bits), beta, gamma
+  v4 bsc;       // weight of the continuation still to be applied at the next visit: brdf, 1/pdf
+  v4 pend[3];   // shadow ray i: pendW, pendInv
+  v4 ray[3];    // rays still to trace: d, t (shadow: tmax; continuation: tbest after the brute-force lists)
+  v4 att[3];    // shadow ray i: attenuation when tinted
+  v4 spare[2];  // (the texture colour of a hit never outlives its visit here)
+};
+static_assert(sizeof(SlotCold) == 256, "SlotCold layout");
+
+// Slot records stream through the cache hierarchy once per visit; PT_SLOT_NT marks their loads/stores
+// non-temporal so that they do not push BVH nodes out of the 4 MB L2 of the XCD.
+#ifndef PT_SLOT_NT
+#define PT_SLOT_NT 0
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ T slot_load(const T* p) {
+  static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+  if constexpr (PT_SLOT_NT) {
+    T out;
+    const f4v* src = reinterpret_cast<const f4v*>(p); f4v* dst = reinterpret_cast<f4v*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) dst[i] = __builtin_nontemporal_load(src + i);
+    return out;
+  } else {
+    return *p;
+  }
+}
+template <class T> __device__ __forceinline__ void slot_store(T* p, const T& v) {
+  static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+  if constexpr (PT_SLOT_NT) {
+    const f4v* src = reinterpret_cast<const f4v*>(&v); f4v* dst = reinterpret_cast<f4v*>(p);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) __builtin_nontemporal_store(src[i], dst + i);
+  } else {
+    *p = v;
+  }
+}
+
+// LDS image of NS slots
+template <int NS>
+struct PoolLds {
+  // only what the node loop touches lives in LDS: 32 B + the stack per slot
+  v4 nodeA[NS];           // o.xyz, tbest
+  v4 nodeB[NS];           // d.xyz, node (int bits); a lane that picks the slot up for the node loop derives 1/d from it
+  int stack[NS][kStackN + 1];   // [0] = sp | packet description (see the flag bits below), [1..] = entries
+  unsigned short queue[kNumQ][ring_capacity(NS)];
+  int qHead[kNumQ], qCount[kNumQ];   // SHARED only
+  int done, lock;                    // SHARED only
+};
+
+template <int NS>
+struct WavePriv {
+  unsigned short qnode[ring_capacity(NS)];   // node-ready slots owned by this wave (ring)
+  // One loop iteration pushes at most 128 slots (results of the last pass + lanes leaving the node loop).
+  unsigned short qleaf[256];       // slots standing at a leaf, owned by this wave (ring; a pass runs at 64: < 64 + 128)
+  unsigned short outbox[2][160];   // slots on their way to the pool's Q_SHADE / Q_GEN (flushed at 32: < 32 + 128)
+};
+
+typedef __attribute__((address_space(3))) int lds_int;
+
+// The LDS part is addressed through an address_space(3) pointer so that push/pop compile to
+// ds_write_b32/ds_read_b32 (a generic pointer makes the compiler merge the LDS and the HBM
+// overflow path into one flat_load).
+// stack[slot][0]: bits 0-7 stack pointer, the rest describes the packet in flight
+constexpr int kSpMask = 0xff;
+constexpr int kShadeFlag = 1 << 30;   // the finished packet goes to Q_SHADE (it had shadow rays or its continuation hit something), not Q_GEN
+constexpr int kShadowRay = 1 << 29;   // the ray in flight is a shadow ray (MinimalOptiX.h:48 RAY_TYPE_SHADOW)
+constexpr int kHitValid = 1 << 28;    // SlotCold::hit holds the continuation's nearest hit so far
+constexpr int kCurShift = 8;          // bits 8-9: index of the ray in flight within the packet (shadow rays first)
+constexpr int kNShShift = 10;         // bits 10-11: shadow rays in the packet
+constexpr int kNRayShift = 12;        // bits 12-13: rays in the packet - 1
+constexpr int kStatShift = 14;        // bits 14-19: per shadow ray 0 = attenuation (1,1,1), 1 = (0,0,0), 2 = tinted (att row)
+constexpr int kHasScale = 1 << 20;    // SlotCold::bsc holds the continuation's weight (a Disney bounce)
+constexpr int kSwitchRef = (int)0x80000000;   // "node" of a slot whose ray ended while another ray of the packet is pending
+__device__ __forceinline__ int fl_cur(int fl) { return (fl >> kCurShift) & 3; }
+__device__ __forceinline__ int fl_nsh(int fl) { return (fl >> kNShShift) & 3; }
+__device__ __forceinline__ int fl_nray(int fl) { return ((fl >> kNRayShift) & 3) + 1; }
+__device__ __forceinline__ int fl_stat(int fl, int i) { return (fl >> (kStatShift + 2 * i)) & 3; }
+__device__ __forceinline__ bool fl_more(int fl) { return fl_cur(fl) + 1 < fl_nray(fl); }     // another ray of the packet is pending
+
+struct SlotStack {
+  lds_int* lds;           // &stack[slot][1]
+  int* ovf;               // this slot's overflow area in HBM (or nullptr)
+  __device__ __forceinline__ void store(int sp, int v) {
+    if (__builtin_expect(sp < kStackN, 1)) lds[sp] = v; else ovf[sp - kStackN] = v;
+  }
+  __device__ __forceinline__ int load(int sp) const {
+    int v;
+    if (__builtin_expect(sp < kStackN, 1)) v = lds[sp]; else v = ovf[sp - kStackN];
+    return v;
+  }
+};
+
+__device__ __forceinline__ float node_inv(float d) {      // slab_inv (pt_path.h) with the hardware reciprocal
+  return __builtin_amdgcn_rcpf(__builtin_fabsf(d) < 1e-30f ? __builtin_copysignf(1e-30f, d) : d);
+}
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// destination queue of a slot after a traversal step / a ray set-up
+__device__ __forceinline__ int route(int node, int kind, int bestPrim) {
+  if (node == kTravDone) return (kind == RK_SHADOW || bestPrim >= 0) ? Q_SHADE : Q_GEN;
+  return node >= 0 ? Q_NODE : Q_LEAF;
+}
+
+template <bool CNT, bool SHARED, bool FAST = false>
+__global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(const LaunchArgs a) {
+  constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
+  constexpr int RC = ring_capacity(NS);                  // ring capacity (power of two >= NS)
+  __shared__ PoolLds<NS> sPool[SHARED ? 1 : kWaves];
+  __shared__ WavePriv<NS> sPriv[kWaves];
+
+  const SceneView& sc = a.scene;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  PoolLds<NS>& W = sPool[SHARED ? 0 : wave];
+  const int gpool = SHARED ? blockIdx.x : blockIdx.x * kWaves + wave;
+  SlotCold* cold = reinterpret_cast<SlotCold*>(a.poolCold) + (size_t)gpool * NS;
+  int* ovfBase = a.stackOverflow ? a.stackOverflow + (size_t)gpool * NS * a.ovfDepth : nullptr;
+
+  // sub-phase clocks of the counting build
+  unsigned long long tLocal = 0, tLock = 0, tTxn = 0, tIdle = 0, tBLoad = 0, tBRun = 0, tBStore = 0, nTxn = 0, nIter = 0;
+  unsigned long long tSub = 0, nIterResult = 0, nIterLights = 0, nIterGen = 0, nodeRuns = 0, ringBacklog = 0, leafBacklog = 0;
+#define PT_SUB0() do { if (CNT) tSub = __builtin_amdgcn_s_memtime(); } while (0)
+#define PT_SUB(acc) do { if (CNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tSub; tSub = now_; } } while (0)
+  // queue bookkeeping: registers (wave-uniform); with SHARED they mirror LDS inside a transaction
+  int qHead[kNumQ] = { 0, 0 }, qCount[kNumQ] = { 0, 0 };
+  int nDone = 0;
+
+  [[maybe_unused]] auto q_push = [&](int q, bool pred, int slot) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return;
+    if (pred) W.queue[q][(qHead[q] + qCount[q] + lane_rank(m)) & (RC - 1)] = (unsigned short)slot;
+    qCount[q] += __popcll(m);
+  };
+  auto q_pop = [&](int q, bool want) -> int {
+    const unsigned long long m = __ballot(want);
+    const int n = min(__popcll(m), qCount[q]);
+    int slot = -1;
+    if (want) { const int r = lane_rank(m); if (r < n) slot = W.queue[q][(qHead[q] + r) & (RC - 1)]; }
+    qHead[q] = (qHead[q] + n) & (RC - 1);
+    qCount[q] -= n;
+    return slot;
+  };
+  auto txn_begin = [&]() {
+    if constexpr (SHARED) {
+      if (lane == 0) { while (atomicCAS(&W.lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1); }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (CNT) { (void)__builtin_amdgcn_readfirstlane(W.lock); PT_SUB(tLock); nTxn++; }
+      for (int q = 0; q < kNumQ; q++) {
+        qHead[q] = __builtin_amdgcn_readfirstlane(W.qHead[q]);
+        qCount[q] = __builtin_amdgcn_readfirstlane(W.qCount[q]);
+      }
+      nDone = __builtin_amdgcn_readfirstlane(W.done);
+    }
+  };
+  auto txn_end = [&]() {
+    if constexpr (SHARED) {
+      if (lane == 0) {
+        for (int q = 0; q < kNumQ; q++) { W.qHead[q] = qHead[q]; W.qCount[q] = qCount[q]; }
+        W.done = nDone;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&W.lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+  auto make_stack = [&](int slot) {
+    SlotStack st;
+    st.lds = (lds_int*)&W.stack[slot][1];
+    st.ovf = ovfBase ? ovfBase + (size_t)slot * a.ovfDepth : nullptr;
+    return st;
+  };
+
+  // ---- start-up: every slot in use needs a work item ----
+  // Paths in flight = slots in use; by Little's law a ray spends (slots in use) / (rays per second) in the scheduler,
+  // about 70 us with all 512 slots of every pool, so a path that bounces to the depth cap (about 1000 dependent rays)
+  // takes 70-90 ms however short the launch is.  A short launch (one rank's share of a multi-GPU frame) therefore
+  // uses fewer slots: a little less throughput, a much shorter critical path (LaunchArgs::slotsInUse, moptix_api.hip).
+  const int nUse = (a.slotsInUse > 0 && a.slotsInUse < NS) ? (SHARED ? a.slotsInUse : max(64, a.slotsInUse / kWaves)) : NS;
+  {
+    const int first = SHARED ? threadIdx.x : lane, step = SHARED ? kBlockThreads : 64;
+    for (int s = first; s < nUse; s += step) {
+      i4 ctl; ctl.x = -1; ctl.y = 0; ctl.z = 0; ctl.w = M_NEW_PIXEL;     // item -1: whatever sample comes first is "new" (rows get written)
+      cold[s].ctl = ctl;
+      W.stack[s][0] = 0;
+      W.queue[Q_GEN][s] = (unsigned short)s;
+    }
+    if constexpr (SHARED) {
+      if (threadIdx.x == 0) {
+        for (int q = 0; q < kNumQ; q++) { W.qHead[q] = 0; W.qCount[q] = 0; }
+        W.qCount[Q_GEN] = nUse; W.done = NS - nUse; W.lock = 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+    } else {
+      qCount[Q_GEN] = nUse; nDone = NS - nUse;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+  }
+
+  Counters ct = {};
+  uint32_t nodeSteps = 0, nodeLanes = 0, leafPasses = 0, leafLanes = 0, batches = 0, batchLanes = 0, idleSpins = 0;
+  unsigned long long tBatch = 0, tSwap = 0, tNode = 0, tLeaf = 0, tStamp = 0;
+  const unsigned long long tStart = CNT ? __builtin_amdgcn_s_memtime() : 0ull;
+  [[maybe_unused]] const unsigned long long rtStart = CNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#define PT_STAMP(acc) do { if (CNT) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tStamp; tStamp = now_; } } while (0)
+  tStamp = tStart;
+
+  // ---- node-loop worker context: the only per-lane state that survives between passes ----
+  int ns = -1;                 // slot this lane is walking, -1 = none
+  int nsFlag = 0;              // packet description bits of that slot (everything above the stack pointer)
+  PathState nray;              // o, tmin used
+  nray.o = mk3(0, 0, 0); nray.tmin = sc.epsT; nray.d = mk3(0, 0, 1); nray.tmax = 0; nray.kind = RK_RADIANCE; nray.mode = M_TRACE;
+  Trav ntv;                    // inv, tbest, node, sp used
+  ntv.node = kTravDone; ntv.sp = 0; ntv.tbest = 0; ntv.inv = mk3(0, 0, 0); ntv.noi = mk3(0, 0, 0); ntv.bestPrim = -1; ntv.bestTri = -1;
+  ntv.beta = 0; ntv.gamma = 0; ntv.att = mk3(1, 1, 1); ntv.started = 1;
+
+  // result of the last pass, queued inside the next transaction
+  int pendSlot = -1, pendDest = DEST_NONE;
+
+  // ---- leaf pass: the slots popped from Q_LEAF stand at a leaf ----
+  auto leaf_pass = [&](int slot) {
+    const bool have = slot >= 0;
+    if (CNT) { leafPasses++; leafLanes += (uint32_t)__popcll(__ballot(have)); }
+    pendSlot = slot; pendDest = DEST_NONE;
+    // slot records written by earlier passes of this wave (other lanes) or published by other waves: the stores
+    // of the previous pass were left in flight, so they are ordered here, where their latency has already elapsed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (have) {
+      const v4 na = W.nodeA[slot], nb = W.nodeB[slot];
+      const int fl = W.stack[slot][0];
+      const int node0 = f2i(nb.w);
+      const bool isSwitch = node0 == kSwitchRef;
+      const bool shadow = (fl & kShadowRay) != 0, hitValid = (fl & kHitValid) != 0;
+      const int cur = fl_cur(fl);
+      const SlotCold* cs = cold + slot;
+      // one round trip: the leaf's triangles and whichever row of the slot record this visit needs
+      LeafChunk ch;
+      leaf_fetch4(sc, isSwitch ? make_leaf_ref(0, 1) : node0, 0, ch);
+      v4 wr = mk4(0.f, 0.f, 1.f, 0.f);
+      if (isSwitch) wr = slot_load(&cs->ray[cur]);                       // ray cur+1 of the packet sits in ray[cur]
+      else if (shadow) { if (fl_stat(fl, cur) == 2) wr = slot_load(&cs->att[cur]); }
+      else if (hitValid) wr = slot_load(&cs->hit);
+      if (isSwitch) {
+        // the packet's next ray: same origin, restart at the root
+        const int nxt = cur + 1;
+        const bool nshadow = nxt < fl_nsh(fl);
+        W.nodeB[slot] = mk4(wr.x, wr.y, wr.z, i2f(sc.rootRef));
+        W.nodeA[slot].w = wr.w;
+        W.stack[slot][0] = (fl & ~(kSpMask | (3 << kCurShift) | kShadowRay)) | (nxt << kCurShift) | (nshadow ? kShadowRay : 0);
+        pendDest = sc.rootRef >= 0 ? Q_NODE : Q_LEAF;
+      } else {
+        PathState ps; Trav tv;
+        ps.tmin = sc.epsT; ps.mode = M_TRACE;
+        ps.o = mk3(na.x, na.y, na.z); ps.d = mk3(nb.x, nb.y, nb.z);
+        ps.kind = shadow ? RK_SHADOW : RK_RADIANCE;
+        ps.tmax = shadow ? na.w : kRtDefaultMax;
+        tv.inv = mk3(0.f, 0.f, 0.f); tv.tbest = na.w;      // the leaf step does not use 1/d
+        tv.node = node0; tv.sp = fl & kSpMask;
+        tv.bestTri = -1; tv.bestPrim = -1; tv.beta = 0.f; tv.gamma = 0.f; tv.att = mk3(1.f, 1.f, 1.f);
+        if (shadow) { if (fl_stat(fl, cur) == 2) tv.att = mk3(wr.x, wr.y, wr.z); }
+        else if (hitValid) { tv.bestTri = f2i(wr.x); tv.bestPrim = f2i(wr.y); tv.beta = wr.z; tv.gamma = wr.w; }
+        const int oldTri = tv.bestTri, oldPrim = tv.bestPrim;
+        const v3 oldAtt = tv.att;
+        SlotStack st = make_stack(slot);
+        trav_leaf_step_fetched<CNT>(sc, ps, tv, st, ct, ch);
+        int nfl = fl & ~kSpMask;
+        if (shadow) {
+          if (tv.att.x != oldAtt.x || tv.att.y != oldAtt.y || tv.att.z != oldAtt.z) {
+            const bool zero = tv.att.x == 0.f && tv.att.y == 0.f && tv.att.z == 0.f;      // disneyAnyHit on an opaque surface
+            nfl = (nfl & ~(3 << (kStatShift + 2 * cur))) | ((zero ? 1 : 2) << (kStatShift + 2 * cur));
+            if (!zero) slot_store(&cold[slot].att[cur], mk4(tv.att.x, tv.att.y, tv.att.z, 0.f));
+          }
+        } else if (tv.bestTri != oldTri || tv.bestPrim != oldPrim) {
+          // most leaf visits find nothing nearer: the hit row is only written when it changed (beta / gamma change with bestTri)
+          slot_store(&cold[slot].hit, mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma));
+          nfl |= kHitValid | kShadeFlag;
+        }
+        int nodeOut = tv.node;
+        if (tv.node == kTravDone && fl_more(fl)) nodeOut = kSwitchRef;      // this ray is done, the packet is not
+        W.nodeA[slot].w = tv.tbest;
+        W.nodeB[slot].w = i2f(nodeOut);
+        W.stack[slot][0] = tv.sp | nfl;
+        pendDest = nodeOut == kTravDone ? ((nfl & kShadeFlag) ? Q_SHADE : Q_GEN) : (nodeOut >= 0 ? Q_NODE : Q_LEAF);
+      }
+    }
+    // Slot records in HBM are re-read by other lanes / waves.  With a shared pool a slot only reaches another wave
+    // through a queue transaction, whose release fence (txn_end) covers these stores: no wait here, the store
+    // latency overlaps with the bookkeeping that follows.
+    if constexpr (!SHARED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  };
+
+  // ---- shading / regeneration batch: run the path state machine for the popped slots ----
+  auto run_batch = [&](int slot, bool shadeBatch) {
+    const bool have = slot >= 0;
+    if (CNT) { batches++; batchLanes += (uint32_t)__popcll(__ballot(have)); }
+    PT_SUB0();
+    pendSlot = slot; pendDest = DEST_NONE;
+    PathState ps; Trav res;
+    ps.mode = M_DONE; ps.kind = RK_RADIANCE;
+    res.node = kTravDone; res.bestPrim = -1;
+    // slot records written by earlier passes of this wave (other lanes) or published by other waves: the stores
+    // of the previous pass were left in flight, so they are ordered here, where their latency has already elapsed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    Packet pk; packet_clear(pk);
+    v3 att[kPacketShadows] = { mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f) };
+    if (have) {
+      const SlotCold* cs = cold + slot;
+      const int fl = W.stack[slot][0];
+      const bool hitValid = (fl & kHitValid) != 0;
+      const int nSh = fl_nsh(fl);                      // 0 for a slot that waits for a work item (flags are cleared then)
+      const i4 ctl = slot_load(&cs->ctl);
+      const v4 thrIn = slot_load(&cs->thr), radIn = slot_load(&cs->rad);
+      v4 wh = mk4(0.f, 0.f, 0.f, 0.f), wb = mk4(1.f, 1.f, 1.f, 1.f);
+      v4 wp[kPacketShadows], wa[kPacketShadows];
+      if (hitValid) wh = slot_load(&cs->hit);
+      if (fl & kHasScale) wb = slot_load(&cs->bsc);
+#pragma unroll
+      for (int i = 0; i < kPacketShadows; i++) {
+        wp[i] = mk4(0.f, 0.f, 0.f, 0.f); wa[i] = mk4(1.f, 1.f, 1.f, 0.f);
+        if (i < nSh) {
+          wp[i] = slot_load(&cs->pend[i]);
+          const int stt = fl_stat(fl, i);
+          if (stt == 2) wa[i] = slot_load(&cs->att[i]);
+          else if (stt == 1) wa[i] = mk4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      const v4 na = W.nodeA[slot], wd = W.nodeB[slot];
+      ps.mode = ctl.w & 7; ps.light = 0; ps.item = ctl.x; ps.depth = ctl.y; ps.seed = (uint32_t)ctl.z; ps.pixel = 0;
+      pk.nShadow = (ctl.w >> 3) & 3; pk.hasBounce = (ctl.w >> 5) & 1; pk.hasScale = (ctl.w >> 6) & 1;
+      pk.bscale = mk3(wb.x, wb.y, wb.z); pk.binv = wb.w;
+#pragma unroll
+      for (int i = 0; i < kPacketShadows; i++) { pk.pendW[i] = mk3(wp[i].x, wp[i].y, wp[i].z); pk.pendInv[i] = wp[i].w; att[i] = mk3(wa[i].x, wa[i].y, wa[i].z); }
+      ps.thr = mk3(thrIn.x, thrIn.y, thrIn.z); ps.rad = mk3(radIn.x, radIn.y, radIn.z);
+      ps.N = mk3(0.f, 0.f, 1.f); ps.mat = 0; ps.V = mk3(0.f, 0.f, 1.f);
+      ps.pendW = mk3(0.f, 0.f, 0.f); ps.pendInv = 0.f; ps.accum = mk3(0, 0, 0); ps.cdlin = mk3(0.f, 0.f, 0.f);
+      // the continuation is the packet's last ray: its origin, direction and tbest are what LDS holds now
+      ps.o = mk3(na.x, na.y, na.z); ps.d = mk3(wd.x, wd.y, wd.z); ps.tmin = sc.epsT; ps.tmax = kRtDefaultMax;
+      ps.kind = RK_RADIANCE;
+      res.tbest = na.w; res.bestTri = -1; res.bestPrim = -1; res.beta = 0.f; res.gamma = 0.f; res.att = mk3(1.f, 1.f, 1.f);
+      if (hitValid) { res.bestTri = f2i(wh.x); res.bestPrim = f2i(wh.y); res.beta = wh.z; res.gamma = wh.w; }
+      if (ps.mode == M_TRACE) ps.mode = M_RESULT;
+    }
+    if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBLoad); }
+    for (;;) {
+      if (have && ps.mode == M_NEW_SAMPLE) {
+        if (CNT) {      // finish-time histogram (1 ms buckets): how many samples end when, and how deep they were
+          const unsigned long long b = min(255ull, (__builtin_amdgcn_s_memrealtime() - rtStart) / 100000ull);
+          atomicAdd(a.counters + 40 + b, 1ull); atomicMax(a.counters + 296 + b, (unsigned long long)ps.depth); atomicAdd(a.counters + 552 + b, (unsigned long long)ps.depth);
+        }
+        store_sample(a, ps.item, ps.accum);
+        if (a.tileCost != nullptr && ps.depth >= kDeepPath) atomicMax(a.tileCost + ((ps.item % a.nItems) >> a.unitShift), (unsigned int)ps.depth);
+        ps.mode = M_NEW_PIXEL;
+      }
+      // lanes that arrive with a finished packet go first; the lanes that only need a new work item wait for them, so
+      // that begin_sample + the ray set-up run once, for all of them together
+      const bool resultFirst = __ballot(have && ps.mode == M_RESULT) != 0ull;
+      const bool run = have && ps.mode != M_TRACE && ps.mode != M_DONE &&
+                       !((shadeBatch || resultFirst) && ps.mode == M_NEW_PIXEL);
+      if (__ballot(run) == 0ull) break;
+      if (CNT) {   // which state-machine stages this iteration executes (wave level)
+        if (__ballot(run && ps.mode == M_RESULT)) nIterResult++;
+        if (__ballot(run && ps.mode == M_NEW_PIXEL)) nIterGen++;
+      }
+      if (run) {
+        if (ps.mode == M_RESULT) {
+          on_result_packet<CNT, FAST>(sc, ps, pk, res, att, ct);
+        } else {  // M_NEW_PIXEL: next (pixel, sample) work item
+          int k = atomicAdd(a.workCounter, 1);
+          k = (k >= a.nWork) ? -1 : handout_to_item(a, k);
+          if (CNT && k < 0) atomicMin(a.counters + 37, (unsigned long long)__builtin_amdgcn_s_memrealtime());   // first time the items ran out
+          int s;
+          if (k < 0) { ps.mode = M_DONE; }
+          else if (item_to_pixel(a, k, s, ps.pixel)) { ps.item = k; begin_sample<CNT>(sc, ps, a.seeds[s], ct); packet_primary(pk); }
+        }
+      }
+    }
+    if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBRun); }
+    if (have) {
+      SlotCold* cw = cold + slot;
+      i4 ctl; ctl.x = ps.item; ctl.y = ps.depth; ctl.z = (int)ps.seed;
+      ctl.w = ps.mode | (pk.nShadow << 3) | (pk.hasBounce << 5) | (pk.hasScale << 6);
+      slot_store(&cw->ctl, ctl);
+      slot_store(&cw->thr, mk4(ps.thr.x, ps.thr.y, ps.thr.z, 0.f));
+      slot_store(&cw->rad, mk4(ps.rad.x, ps.rad.y, ps.rad.z, 0.f));
+      if (ps.mode == M_TRACE) {
+        // new packet: the brute-force lists for the continuation (radiance) ray, then the rays in trace order: shadow rays
+        // in light order, the continuation last; the first goes to LDS, the others to the ray rows
+        float tb0 = kRtDefaultMax; int bp0 = -1;
+        if (pk.hasBounce) {
+          Trav tv;
+          ps.kind = RK_RADIANCE;
+          trav_begin<CNT>(sc, ps, tv, ct);
+          tb0 = tv.tbest; bp0 = tv.bestPrim;
+        }
+        const bool hitNow = bp0 >= 0;
+        if (hitNow) slot_store(&cw->hit, mk4(i2f(-1), i2f(bp0), 0.f, 0.f));
+        const int nRays = pk.nShadow + pk.hasBounce;
+        const v4 rb = mk4(ps.d.x, ps.d.y, ps.d.z, tb0);                                     // the continuation
+        const v4 r0 = pk.nShadow > 0 ? mk4(pk.sd[0].x, pk.sd[0].y, pk.sd[0].z, pk.stmax[0]) : rb;   // first ray of the list
+#pragma unroll
+        for (int j = 0; j < kPacketShadows; j++)
+          if (j < pk.nShadow) slot_store(&cw->pend[j], mk4(pk.pendW[j].x, pk.pendW[j].y, pk.pendW[j].z, pk.pendInv[j]));
+        // ray j of the list (j >= 1) goes to ray[j-1]: shadow ray j while j < nShadow, then the continuation
+        if (pk.nShadow > 1) slot_store(&cw->ray[0], mk4(pk.sd[1].x, pk.sd[1].y, pk.sd[1].z, pk.stmax[1]));
+        else if (pk.nShadow == 1 && pk.hasBounce) slot_store(&cw->ray[0], rb);
+        if (pk.nShadow > 2) slot_store(&cw->ray[1], mk4(pk.sd[2].x, pk.sd[2].y, pk.sd[2].z, pk.stmax[2]));
+        else if (pk.nShadow == 2 && pk.hasBounce) slot_store(&cw->ray[1], rb);
+        if (pk.nShadow == 3 && pk.hasBounce) slot_store(&cw->ray[2], rb);
+        if (pk.hasScale) slot_store(&cw->bsc, mk4(pk.bscale.x, pk.bscale.y, pk.bscale.z, pk.binv));
+        W.nodeA[slot] = mk4(ps.o.x, ps.o.y, ps.o.z, r0.w);
+        W.nodeB[slot] = mk4(r0.x, r0.y, r0.z, i2f(sc.rootRef));
+        W.stack[slot][0] = (pk.nShadow << kNShShift) | ((nRays - 1) << kNRayShift) | (pk.nShadow > 0 ? kShadowRay : 0) |
+                           (hitNow ? kHitValid : 0) | ((pk.nShadow > 0 || hitNow) ? kShadeFlag : 0) | (pk.hasScale ? kHasScale : 0);
+        pendDest = sc.rootRef >= 0 ? Q_NODE : Q_LEAF;
+      } else {
+        W.stack[slot][0] = 0;
+        pendDest = (ps.mode == M_NEW_PIXEL) ? Q_GEN : DEST_DONE;
+      }
+    }
+    if constexpr (!SHARED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    PT_SUB(tBStore);
+  };
+
+  // per-wave private structures: the node-ready ring (slots produced by this wave's own passes
+  // stay with the wave) and the out-boxes that collect slots for the pool-wide queues between
+  // two transactions
+  unsigned short* myNodeQ = sPriv[wave].qnode;
+  int nqHead = 0, nqCount = 0;
+  unsigned short* myLeafQ = sPriv[wave].qleaf;
+  int lqHead = 0, lqCount = 0;             // leaf-ready ring: leaf passes need no queue transaction
+  int obCount[2] = { 0, 0 };               // out-boxes for Q_SHADE, Q_GEN
+  int localDone = 0;
+  auto local_push = [&](int dest, int slot) {   // wave-collective; dest per lane
+    {
+      const unsigned long long m = __ballot(dest == Q_NODE);
+      if (m != 0ull) {
+        if (dest == Q_NODE) myNodeQ[(nqHead + nqCount + lane_rank(m)) & (RC - 1)] = (unsigned short)slot;
+        nqCount += __popcll(m);
+      }
+    }
+    {
+      const unsigned long long m = __ballot(dest == Q_LEAF);
+      if (m != 0ull) {
+        if (dest == Q_LEAF) myLeafQ[(lqHead + lqCount + lane_rank(m)) & 255] = (unsigned short)slot;
+        lqCount += __popcll(m);
+      }
+    }
+    for (int d = 0; d < 2; d++) {
+      const unsigned long long m = __ballot(dest == Q_SHADE + d);
+      if (m != 0ull) {
+        if (dest == Q_SHADE + d) sPriv[wave].outbox[d][obCount[d] + lane_rank(m)] = (unsigned short)slot;
+        obCount[d] += __popcll(m);
+      }
+    }
+    localDone += __popcll(__ballot(dest == DEST_DONE));
+  };
+
+  unsigned int guard = 0;
+  const unsigned long long wdStart = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    // bounded in wall-clock time (never hang the GPU): checked every 4096 iterations
+    if ((++guard & 4095u) == 0u && __builtin_amdgcn_s_memrealtime() - wdStart > a.watchdogTicks) { if (lane == 0) atomicOr(a.workCounter + 1, 1); break; }
+    PT_SUB0(); if (CNT) nIter++;
+    // ---- local bookkeeping (no lock): results of the last pass, swap, refill ----
+    if (__ballot(pendDest != DEST_NONE) != 0ull) { local_push(pendDest, pendSlot); pendDest = DEST_NONE; }
+    {
+      const bool leave = ns >= 0 && !(ntv.node >= 0 && ntv.node != kTravDone);
+      if (__ballot(leave) != 0ull) {
+        int dest = DEST_NONE;
+        if (leave) {
+          const int nodeOut = (ntv.node == kTravDone && fl_more(nsFlag)) ? kSwitchRef : ntv.node;   // ray done, packet not: the leaf pass switches rays
+          W.nodeB[ns].w = i2f(nodeOut); W.stack[ns][0] = ntv.sp | nsFlag;
+          dest = (nodeOut == kTravDone) ? ((nsFlag & kShadeFlag) ? Q_SHADE : Q_GEN) : Q_LEAF;   // a lane leaves at a leaf, at a ray switch or finished
+        }
+        local_push(dest, ns);
+        if (leave) ns = -1;
+      }
+      if (nqCount > 0 && __ballot(ns < 0) != 0ull) {
+        const unsigned long long m = __ballot(ns < 0);
+        const int n = min(__popcll(m), nqCount);
+        if (ns < 0) {
+          const int r = lane_rank(m);
+          if (r < n) {
+            ns = myNodeQ[(nqHead + r) & (RC - 1)];
+            const v4 na = W.nodeA[ns], nb = W.nodeB[ns];
+            const int spw = W.stack[ns][0];
+            nray.o = mk3(na.x, na.y, na.z); ntv.tbest = na.w;
+            // 1/d by v_rcp_f32 (1 ulp): the slab test is conservative by far more than that (boxes are padded by 1e-5 of
+            // the scene, pt_lbvh.h pad_lo/pad_hi), and which boxes are entered never changes the result (rule D5)
+            ntv.inv = mk3(node_inv(nb.x), node_inv(nb.y), node_inv(nb.z)); ntv.node = f2i(nb.w);
+            ntv.noi = neg_o_inv(nray.o, ntv.inv);
+            ntv.sp = spw & kSpMask; nsFlag = spw & ~kSpMask;
+          }
+        }
+        nqHead = (nqHead + n) & (RC - 1); nqCount -= n;
+      }
+    }
+    const int nActive = __popcll(__ballot(ns >= 0));
+    const bool starving = nActive <= 64 - a.starveLanes;
+    int pass = -1;      // -1 node loop, 0 leaf, 1 shade, 2 gen, 3 idle, 4 exit
+    int mySlot = -1;
+    auto leaf_pop = [&]() -> int {              // up to 64 slots from this wave's own leaf ring
+      const int n = min(64, lqCount);
+      const int slot = lane < n ? (int)myLeafQ[(lqHead + lane) & 255] : -1;
+      lqHead = (lqHead + n) & 255; lqCount -= n;
+      return slot;
+    };
+    const bool flush = obCount[0] >= 32 || obCount[1] >= 32;      // out-boxes are bounded: flushing comes first
+    if (!flush && (lqCount >= 64 || (starving && lqCount >= 32))) {
+      pass = 0; mySlot = leaf_pop();
+      PT_SUB(tLocal);
+    } else if (starving || flush) {
+      // =========================== queue transaction ===========================
+      PT_SUB(tLocal);
+      txn_begin();
+      for (int d = 0; d < 2; d++) {
+        const int q = Q_SHADE + d;
+        for (int base = 0; base < obCount[d]; base += 64) {
+          const int i = base + lane;
+          if (i < obCount[d]) W.queue[q][(qHead[q] + qCount[q] + i) & (RC - 1)] = sPriv[wave].outbox[d][i];
+        }
+        qCount[q] += obCount[d]; obCount[d] = 0;
+      }
+      nDone += localDone; localDone = 0;
+      if (qCount[Q_SHADE] >= 64) pass = 1;
+      else if (qCount[Q_GEN] >= 64) pass = 2;
+      else if (lqCount >= 64) pass = 0;
+      else if (starving) {
+        const int l = lqCount, sh = qCount[Q_SHADE], g = qCount[Q_GEN];
+        if (l + sh + g == 0) { if (nActive == 0) pass = (nDone == NS) ? 4 : 3; }
+        else pass = (l >= sh && l >= g) ? 0 : (sh >= g ? 1 : 2);
+      }
+      if (pass == 1 || pass == 2) mySlot = q_pop(pass == 1 ? Q_SHADE : Q_GEN, true);
+      txn_end();
+      if (pass == 0) mySlot = leaf_pop();
+      PT_SUB(tTxn);
+      // =========================================================================
+    } else PT_SUB(tLocal);
+    PT_STAMP(tSwap);
+    if (pass == 4) break;
+    if (pass == 3) { if (CNT) idleSpins++; __builtin_amdgcn_s_sleep(32); PT_SUB(tIdle); PT_STAMP(tSwap); continue; }
+    if (pass == 0) { leaf_pass(mySlot); PT_STAMP(tLeaf); continue; }
+    if (pass > 0) { run_batch(mySlot, pass == 1); PT_STAMP(tBatch); continue; }
+
+    // ---- node loop: until swapLanes lanes have left the node set ----
+    if (CNT) { nodeRuns++; ringBacklog += (unsigned long long)nqCount; leafBacklog += (unsigned long long)lqCount; }
+    {
+      SlotStack st = make_stack(ns >= 0 ? ns : 0);
+      for (;;) {
+        const bool atNode = ns >= 0 && ntv.node >= 0 && ntv.node != kTravDone;
+        const unsigned long long m = __ballot(atNode);
+        const int n = __popcll(m);
+        if (n == 0 || nActive - n >= a.swapLanes) break;
+        if (CNT) { nodeSteps++; nodeLanes += (uint32_t)n; }
+        if (atNode) trav_node_step<CNT>(sc, nray, ntv, st, ct);
+      }
+    }
+    PT_STAMP(tNode);
+  }
+
+  if constexpr (CNT) {
+    unsigned long long* c = a.counters;
+    const uint32_t v[9] = { wave_sum(ct.samples), wave_sum(ct.primaryRays), wave_sum(ct.bounceRays), wave_sum(ct.shadowRays),
+                            wave_sum(ct.nodeFetches), wave_sum(ct.triTests), wave_sum(ct.closestHits), wave_sum(ct.lightLoads),
+                            wave_sum(ct.analyticTests) };
+    if (lane == 0) {
+      for (int i = 0; i < 9; i++) atomicAdd(&c[i], (unsigned long long)v[i]);
+      atomicAdd(&c[9], (unsigned long long)nodeSteps + leafPasses);
+      atomicAdd(&c[10], (unsigned long long)nodeLanes + leafLanes);
+      atomicAdd(&c[11], (unsigned long long)batches);
+      atomicAdd(&c[12], (unsigned long long)batchLanes);
+      atomicAdd(&c[14], (unsigned long long)idleSpins);
+      atomicAdd(&c[16], tBatch); atomicAdd(&c[17], tSwap); atomicAdd(&c[18], tNode); atomicAdd(&c[19], tLeaf);
+      atomicAdd(&c[21], __builtin_amdgcn_s_memtime() - tStart);
+      atomicAdd(&c[22], (unsigned long long)leafPasses); atomicAdd(&c[23], (unsigned long long)leafLanes);
+      atomicMax(&c[38], (unsigned long long)__builtin_amdgcn_s_memrealtime());   // last wave out
+      atomicMin(&c[36], rtStart);
+      atomicAdd(&c[24], tLocal); atomicAdd(&c[25], tLock); atomicAdd(&c[26], tTxn); atomicAdd(&c[27], tIdle);
+      atomicAdd(&c[39], nodeRuns); atomicAdd(&c[15], ringBacklog); atomicAdd(&c[13], leafBacklog);
+      atomicAdd(&c[33], nIterResult); atomicAdd(&c[34], nIterLights); atomicAdd(&c[35], nIterGen);
+      atomicAdd(&c[28], tBLoad); atomicAdd(&c[29], tBRun); atomicAdd(&c[30], tBStore); atomicAdd(&c[31], nTxn); atomicAdd(&c[32], nIter);
+    }
+  }
+}
+
+}  // namespace
+
+int packetkernel_lds_stack_entries() { return kStackN; }
+size_t packetkernel_cold_bytes(int nBlocks) { return (size_t)nBlocks * kWaves * kP * sizeof(SlotCold); }
+size_t packetkernel_overflow_ints(int nBlocks, int ovfDepth) { return (size_t)nBlocks * kWaves * kP * (size_t)ovfDepth; }
+
+hipError_t launch_packetkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading) {
+  dim3 grid(nBlocks), block(kBlockThreads);
+  if (fastShading) {
+    if (counted) pt_packetkernel<true, true, true><<<grid, block, 0, stream>>>(a);
+    else         pt_packetkernel<false, true, true><<<grid, block, 0, stream>>>(a);
+  } else {
+    if (counted) pt_packetkernel<true, true, false><<<grid, block, 0, stream>>>(a);
+    else         pt_packetkernel<false, true, false><<<grid, block, 0, stream>>>(a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace pt

@@ -34,6 +34,15 @@ PT_HD void packet_clear(Packet& pk) {
   for (int i = 0; i < kPacketShadows; i++) { pk.sd[i] = mk3(0.f, 0.f, 1.f); pk.stmax[i] = 0.f; pk.pendW[i] = mk3(0.f, 0.f, 0.f); pk.pendInv[i] = 0.f; }
 }
 
+// slot j of the packet, without indexing the arrays by a run-time value (they are meant to live in registers)
+PT_HD void packet_set_shadow(Packet& pk, int j, v3 d, float tmax, v3 w, float inv) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < kPacketShadows; k++)
+    if (k == j) { pk.sd[k] = d; pk.stmax[k] = tmax; pk.pendW[k] = w; pk.pendInv[k] = inv; }
+}
+
 // Material.cu:172-221 for one hit, without the traces (ps.N, ps.V, ps.mat, ps.o set by on_result; ps.light == 0).
 template <bool CNT, bool FAST = false>
 PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Counters& ct) {
@@ -65,14 +74,13 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
       const float lightPdf = lightDst * lightDst / lt->area / dot(normalOnLight, -L);
       const float pdf = disney_pdf<FAST>(m, ps.N, L, H);
       const v3 brdf = disney_eval<FAST>(m, Cdlin, Cspec0, Csheen, onb, L, ps.V, H);
-      const int j = pk.nShadow++;
+      v3 w = mk3(0.f, 0.f, 0.f); float inv = 0.f;
       if (lightPdf > 0 && pdf > 0) {
-        pk.pendW[j] = (brdf * powerHeuristic(lightPdf, pdf)) * lt->emission;
-        pk.pendInv[j] = 1.0f / fmaxf_(0.001f, lightPdf);
-      } else {
-        pk.pendW[j] = mk3(0.f, 0.f, 0.f); pk.pendInv[j] = 0.f;
+        w = (brdf * powerHeuristic(lightPdf, pdf)) * lt->emission;
+        inv = 1.0f / fmaxf_(0.001f, lightPdf);
       }
-      pk.sd[j] = L; pk.stmax[j] = lightDst - sc.epsT;
+      packet_set_shadow(pk, pk.nShadow, L, lightDst - sc.epsT, w, inv);
+      pk.nShadow++;
       cnt<CNT>(ct.shadowRays);
     }
   }
@@ -96,8 +104,11 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
 // Runs until the path owns a new packet (ps.mode == M_TRACE) or the sample has ended (M_NEW_SAMPLE).
 template <bool CNT, bool FAST = false>
 PT_HD void on_result_packet(const SceneView& sc, PathState& ps, Packet& pk, const Trav& tv, const v3 att[kPacketShadows], Counters& ct) {
-  for (int i = 0; i < pk.nShadow; i++) {                          // Material.cu:193-201, light order
-    if (pk.pendInv[i] != 0.f && length(att[i]) != 0.0f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int i = 0; i < kPacketShadows; i++) {                      // Material.cu:193-201, light order
+    if (i < pk.nShadow && pk.pendInv[i] != 0.f && length(att[i]) != 0.0f) {
       const v3 c = (pk.pendW[i] * att[i]) * pk.pendInv[i];
       ps.rad = ps.rad + ps.thr * c;
     }
