@@ -165,6 +165,16 @@ __device__ __forceinline__ int route(int node, int kind, int bestPrim) {
   return node >= 0 ? Q_NODE : Q_LEAF;
 }
 
+// pt_packet.h's sink for the shadow rays of a new packet: see run_batch
+struct SlotSink {
+  SlotCold* cw; v4* nodeA; v4* nodeB; const PathState* ps; int root;
+  __device__ __forceinline__ void shadow(int j, v3 d, float tmax, v3 w, float inv) const {
+    slot_store(&cw->pend[j], mk4(w.x, w.y, w.z, inv));
+    if (j == 0) { *nodeA = mk4(ps->o.x, ps->o.y, ps->o.z, tmax); *nodeB = mk4(d.x, d.y, d.z, i2f(root)); }   // ps->o: the hit point
+    else slot_store(&cw->ray[j - 1], mk4(d.x, d.y, d.z, tmax));
+  }
+};
+
 template <bool CNT, bool SHARED, bool FAST = false>
 __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(const LaunchArgs a) {
   constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
@@ -299,18 +309,24 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       // one round trip: the leaf's triangles and whichever row of the slot record this visit needs
       LeafChunk ch;
       leaf_fetch4(sc, isSwitch ? make_leaf_ref(0, 1) : node0, 0, ch);
-      v4 wr = mk4(0.f, 0.f, 1.f, 0.f);
-      if (isSwitch) wr = slot_load(&cs->ray[cur]);                       // ray cur+1 of the packet sits in ray[cur]
-      else if (shadow) { if (fl_stat(fl, cur) == 2) wr = slot_load(&cs->att[cur]); }
-      else if (hitValid) wr = slot_load(&cs->hit);
-      if (isSwitch) {
-        // the packet's next ray: same origin, restart at the root
+      v4 wr = mk4(0.f, 0.f, 1.f, 0.f), wn = mk4(0.f, 0.f, 1.f, 0.f);
+      const bool more = fl_more(fl);
+      if (more) wn = slot_load(&cs->ray[cur]);                          // ray cur+1 of the packet sits in ray[cur]: needed if this ray ends here
+      if (!isSwitch) {
+        if (shadow) { if (fl_stat(fl, cur) == 2) wr = slot_load(&cs->att[cur]); }
+        else if (hitValid) wr = slot_load(&cs->hit);
+      }
+      // the packet's next ray: same origin, restart at the root
+      auto next_ray = [&](int flags) {
         const int nxt = cur + 1;
-        const bool nshadow = nxt < fl_nsh(fl);
-        W.nodeB[slot] = mk4(wr.x, wr.y, wr.z, i2f(sc.rootRef));
-        W.nodeA[slot].w = wr.w;
-        W.stack[slot][0] = (fl & ~(kSpMask | (3 << kCurShift) | kShadowRay)) | (nxt << kCurShift) | (nshadow ? kShadowRay : 0);
+        const bool nshadow = nxt < fl_nsh(flags);
+        W.nodeB[slot] = mk4(wn.x, wn.y, wn.z, i2f(sc.rootRef));
+        W.nodeA[slot].w = wn.w;
+        W.stack[slot][0] = (flags & ~(kSpMask | (3 << kCurShift) | kShadowRay)) | (nxt << kCurShift) | (nshadow ? kShadowRay : 0);
         pendDest = sc.rootRef >= 0 ? Q_NODE : Q_LEAF;
+      };
+      if (isSwitch) {
+        next_ray(fl);
       } else {
         PathState ps; Trav tv;
         ps.tmin = sc.epsT; ps.mode = M_TRACE;
@@ -338,12 +354,14 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           slot_store(&cold[slot].hit, mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma));
           nfl |= kHitValid | kShadeFlag;
         }
-        int nodeOut = tv.node;
-        if (tv.node == kTravDone && fl_more(fl)) nodeOut = kSwitchRef;      // this ray is done, the packet is not
-        W.nodeA[slot].w = tv.tbest;
-        W.nodeB[slot].w = i2f(nodeOut);
-        W.stack[slot][0] = tv.sp | nfl;
-        pendDest = nodeOut == kTravDone ? ((nfl & kShadeFlag) ? Q_SHADE : Q_GEN) : (nodeOut >= 0 ? Q_NODE : Q_LEAF);
+        if (tv.node == kTravDone && more) {
+          next_ray(nfl);                                                    // this ray is done, the packet is not: on to its next ray
+        } else {
+          W.nodeA[slot].w = tv.tbest;
+          W.nodeB[slot].w = i2f(tv.node);
+          W.stack[slot][0] = tv.sp | nfl;
+          pendDest = tv.node == kTravDone ? ((nfl & kShadeFlag) ? Q_SHADE : Q_GEN) : (tv.node >= 0 ? Q_NODE : Q_LEAF);
+        }
       }
     }
     // Slot records in HBM are re-read by other lanes / waves.  With a shared pool a slot only reaches another wave
@@ -427,7 +445,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       }
       if (run) {
         if (ps.mode == M_RESULT) {
-          on_result_packet<CNT, FAST>(sc, ps, pk, res, att, ct);
+          // a new packet's shadow rays go straight to the slot (SlotSink): weight row, and the ray itself to LDS (the
+          // first one) or to its ray row -- not held in registers across the BRDF evaluations of the lights that follow
+          on_result_packet<CNT, FAST, SlotSink>(sc, ps, pk, res, att, ct, SlotSink{ cold + slot, &W.nodeA[slot], &W.nodeB[slot], &ps, sc.rootRef });
         } else {  // M_NEW_PIXEL: next (pixel, sample) work item
           int k = atomicAdd(a.workCounter, 1);
           k = (k >= a.nWork) ? -1 : handout_to_item(a, k);
@@ -459,20 +479,17 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         const bool hitNow = bp0 >= 0;
         if (hitNow) slot_store(&cw->hit, mk4(i2f(-1), i2f(bp0), 0.f, 0.f));
         const int nRays = pk.nShadow + pk.hasBounce;
-        const v4 rb = mk4(ps.d.x, ps.d.y, ps.d.z, tb0);                                     // the continuation
-        const v4 r0 = pk.nShadow > 0 ? mk4(pk.sd[0].x, pk.sd[0].y, pk.sd[0].z, pk.stmax[0]) : rb;   // first ray of the list
-#pragma unroll
-        for (int j = 0; j < kPacketShadows; j++)
-          if (j < pk.nShadow) slot_store(&cw->pend[j], mk4(pk.pendW[j].x, pk.pendW[j].y, pk.pendW[j].z, pk.pendInv[j]));
-        // ray j of the list (j >= 1) goes to ray[j-1]: shadow ray j while j < nShadow, then the continuation
-        if (pk.nShadow > 1) slot_store(&cw->ray[0], mk4(pk.sd[1].x, pk.sd[1].y, pk.sd[1].z, pk.stmax[1]));
-        else if (pk.nShadow == 1 && pk.hasBounce) slot_store(&cw->ray[0], rb);
-        if (pk.nShadow > 2) slot_store(&cw->ray[1], mk4(pk.sd[2].x, pk.sd[2].y, pk.sd[2].z, pk.stmax[2]));
-        else if (pk.nShadow == 2 && pk.hasBounce) slot_store(&cw->ray[1], rb);
-        if (pk.nShadow == 3 && pk.hasBounce) slot_store(&cw->ray[2], rb);
+        const v4 rb = mk4(ps.d.x, ps.d.y, ps.d.z, tb0);                                     // the continuation: last ray of the list
+        if (pk.nShadow == 0) {                                                              // ... and the first one here
+          W.nodeA[slot] = mk4(ps.o.x, ps.o.y, ps.o.z, rb.w);
+          W.nodeB[slot] = mk4(rb.x, rb.y, rb.z, i2f(sc.rootRef));
+        } else if (pk.hasBounce) {
+          // the shadow rays are in place already (SlotSink); ray j >= 1 of the list lives in ray[j-1]
+          if (pk.nShadow == 1) slot_store(&cw->ray[0], rb);
+          else if (pk.nShadow == 2) slot_store(&cw->ray[1], rb);
+          else slot_store(&cw->ray[2], rb);
+        }
         if (pk.hasScale) slot_store(&cw->bsc, mk4(pk.bscale.x, pk.bscale.y, pk.bscale.z, pk.binv));
-        W.nodeA[slot] = mk4(ps.o.x, ps.o.y, ps.o.z, r0.w);
-        W.nodeB[slot] = mk4(r0.x, r0.y, r0.z, i2f(sc.rootRef));
         W.stack[slot][0] = (pk.nShadow << kNShShift) | ((nRays - 1) << kNRayShift) | (pk.nShadow > 0 ? kShadowRay : 0) |
                            (hitNow ? kHitValid : 0) | ((pk.nShadow > 0 || hitNow) ? kShadeFlag : 0) | (pk.hasScale ? kHasScale : 0);
         pendDest = sc.rootRef >= 0 ? Q_NODE : Q_LEAF;

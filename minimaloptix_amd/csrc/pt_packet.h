@@ -43,9 +43,17 @@ PT_HD void packet_set_shadow(Packet& pk, int j, v3 d, float tmax, v3 w, float in
     if (k == j) { pk.sd[k] = d; pk.stmax[k] = tmax; pk.pendW[k] = w; pk.pendInv[k] = inv; }
 }
 
+// Where a new packet's shadow rays go: into the Packet (host mirror, tests) ...
+struct PacketSink {
+  Packet& pk;
+  PT_HD void shadow(int j, v3 d, float tmax, v3 w, float inv) const { packet_set_shadow(pk, j, d, tmax, w, inv); }
+};
+// ... or wherever the caller keeps them (packetkernel.hip writes each one to the slot record as soon as it is known,
+// so that the three of them are not held in registers across the BRDF evaluations that follow).
+
 // Material.cu:172-221 for one hit, without the traces (ps.N, ps.V, ps.mat, ps.o set by on_result; ps.light == 0).
-template <bool CNT, bool FAST = false>
-PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Counters& ct) {
+template <bool CNT, bool FAST = false, class Sink = PacketSink>
+PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Counters& ct, const Sink& sink) {
   const DevMaterial& m = sc.mats[ps.mat];
   packet_clear(pk);
   const Onb onb = make_onb(ps.N);
@@ -79,7 +87,7 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
         w = (brdf * powerHeuristic(lightPdf, pdf)) * lt->emission;
         inv = 1.0f / fmaxf_(0.001f, lightPdf);
       }
-      packet_set_shadow(pk, pk.nShadow, L, lightDst - sc.epsT, w, inv);
+      sink.shadow(pk.nShadow, L, lightDst - sc.epsT, w, inv);
       pk.nShadow++;
       cnt<CNT>(ct.shadowRays);
     }
@@ -102,8 +110,9 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
 
 // The packet has been traced: att[i] = attenuation of shadow ray i (disneyAnyHit), tv = nearest hit of the continuation.
 // Runs until the path owns a new packet (ps.mode == M_TRACE) or the sample has ended (M_NEW_SAMPLE).
-template <bool CNT, bool FAST = false>
-PT_HD void on_result_packet(const SceneView& sc, PathState& ps, Packet& pk, const Trav& tv, const v3 att[kPacketShadows], Counters& ct) {
+template <bool CNT, bool FAST = false, class Sink = PacketSink>
+PT_HD void on_result_packet(const SceneView& sc, PathState& ps, Packet& pk, const Trav& tv, const v3 att[kPacketShadows], Counters& ct,
+                            const Sink& sink) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -117,7 +126,7 @@ PT_HD void on_result_packet(const SceneView& sc, PathState& ps, Packet& pk, cons
   if (pk.hasScale) ps.thr = (ps.thr * pk.bscale) * pk.binv;      // Material.cu:217-219 indirect = brdf * child / pdf
   ps.kind = RK_RADIANCE;
   on_result<CNT>(sc, ps, tv, ct);
-  if (ps.mode == M_LIGHTS) { on_lights_packet<CNT, FAST>(sc, ps, pk, ct); return; }
+  if (ps.mode == M_LIGHTS) { on_lights_packet<CNT, FAST, Sink>(sc, ps, pk, ct, sink); return; }
   if (ps.mode == M_TRACE) { packet_clear(pk); pk.hasBounce = 1; }       // glass / lambertian / metal: the continuation only
 }
 

@@ -364,7 +364,7 @@ int hostsim_render_timed(const hostsim_scene* s, int leafSize, const int32_t* se
           while (tv.node != kTravDone) trav_step<true>(sc, ps, tv, st, ct);
           ps.mode = M_RESULT;
         } else if (ps.mode == M_RESULT && g_packet) {
-          on_result_packet<true>(sc, ps, pk, tv, att, ct);
+          on_result_packet<true>(sc, ps, pk, tv, att, ct, PacketSink{ pk });
         } else if (ps.mode == M_RESULT) {
           on_result<true>(sc, ps, tv, ct);
         } else if (ps.mode == M_LIGHTS) {

@@ -103,7 +103,7 @@ def _sphere_light_scene(tmp_path):
     return str(tmp_path / "scenes") + "/"
 
 
-@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("variant", [0, 3, 4])
 def test_sphere_light_next_event_estimation(gpu_ctx, tmp_path, variant):
     """Material.cu:176-178: a sphere light is sampled at position + randInUnitSphere * radius (3 draws per attempt),
     next to a quad light (2 draws); shadow rays pass a Disney glass pane (disneyAnyHit tint).  The sphere light's own
@@ -301,3 +301,22 @@ def test_analytic_scenes_through_the_queue_kernel(gpu_ctx):
     assert np.array_equal(got, ref)
     o, _ = oracle_scene(hs).render(seeds)
     assert rmse(got / 3, o / 3) <= RMSE_TIGHT
+
+
+def test_packet_variant_on_the_glass_and_million_triangle_scenes(gpu_ctx):
+    """Kernel variant 4 (one shading visit per bounce, pt_packet.h) on the scenes with glass in the shadow rays' way
+    (attenuation rows) and with a sphere light: same bits and the same counters as the default kernel."""
+    for kind, kw, res in (("coffee_pot_standin", {}, (240, 135)), ("million_standin", dict(iarg=60000), (200, 112)), ("dining_standin", dict(iarg=2), (200, 112))):
+        hs = M.HostScene(kind, res[0], res[1], **kw)
+        seeds = M.launch_seeds(3)
+        out = {}
+        try:
+            for v in (3, 4):
+                gpu_ctx.set_option("kernel_variant", v)
+                gpu_ctx.load(hs)
+                out[v] = _render(gpu_ctx, seeds, counted=True)
+        finally:
+            gpu_ctx.set_option("kernel_variant", 3)
+        assert np.array_equal(out[3][0], out[4][0]), kind
+        for f in ("primaryRays", "bounceRays", "shadowRays", "closestHits", "lightLoads", "samples"):
+            assert getattr(out[3][1], f) == getattr(out[4][1], f), (kind, f)

@@ -43,10 +43,11 @@ def test_render_matches_oracle(gpu_ctx, kind, kw, res, spp):
     assert np.array_equal(gpu_ctx.accum_read(), g)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_all_kernel_variants_are_bit_identical(gpu_ctx, variant):
-    """The four schedulers (per-lane, per-wave pool, slot queues, workgroup-shared queues) run the
-    same per-path arithmetic: identical images, identical ray counts, and parity with the oracle."""
+    """The five schedulers (per-lane, per-wave pool, slot queues, workgroup-shared queues, and the per-bounce packets
+    of pt_packet.h on the shared queues) run the same per-path arithmetic: identical images, identical ray counts,
+    and parity with the oracle."""
     hs = M.HostScene("file:coffee", 200, 112)
     seeds = M.launch_seeds(3)
     default = gpu_ctx.get_option("kernel_variant")
@@ -194,7 +195,7 @@ def _tiny_scene(tmp_path, n_tris):
 
 
 @pytest.mark.parametrize("n_tris", [1, 3, 5, 9])
-@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("variant", [0, 3, 4])
 def test_tiny_meshes_root_leaf_and_shallow_trees(gpu_ctx, tmp_path, n_tris, variant):
     base = _tiny_scene(tmp_path, n_tris)
     hs = M.HostScene("file:cornell", 96, 64, base_folder=base)
@@ -236,7 +237,7 @@ def test_odd_frame_sizes_and_partitions(gpu_ctx):
     assert np.array_equal(parts, whole)                    # tile split is bit-identical to one GPU
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_textured_scene_matches_oracle(gpu_ctx, tmp_path, variant):
     """albedo textures (rtTex2D, repeat + bilinear) on Disney and Disney-glass meshes."""
     from common import textured_scene
