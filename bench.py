@@ -270,7 +270,7 @@ def main():
             "config": {"workload": "coffee.obj LBVH build+traverse, %dx%d, %d spp (BASELINE.json configs[2])" % (W, H, a.spp),
                        "scene": a.scene, "width": W, "height": H, "spp": a.spp, "rays_per_frame": int(total_rays),
                        "parallelism": par, "split": a.split if world > 1 else None, "pipeline": bool(pipeline),
-                       "kernel_variant": ctx.get_option("kernel_variant"), "bvh_nodes": int(info.nNodes), "bvh_depth": int(info.treeDepth),
+                       "kernel_variant": ctx.get_option("kernel_variant_used"), "bvh_nodes": int(info.nNodes), "bvh_depth": int(info.treeDepth),
                        "bvh_build_ms": round(float(info.buildMs), 3), "ms_per_frame": round(ms_per_step, 3),
                        "source_hash": source_hash(REPO)},
             "roofline": roof,

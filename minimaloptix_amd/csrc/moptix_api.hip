@@ -83,6 +83,9 @@ struct moptix_context_t {
   int optFastShading = 0;
   int optBuilder = 1;
   int optAnalyticQueue = 0;
+  int optAutoPacket = 1;
+  int lastVariant = -1;              // what the last render ran (get_option "kernel_variant_used")
+  bool variantExplicit = false;      // kernel_variant was set by the caller: no automatic choice
   int optSlotsInUse = -1;            // -1 = chosen per launch from its size
   double kernelMs = 0.0, reduceMs = 0.0; uint64_t nLaunches = 0;
   bool asyncPending = false;
@@ -212,8 +215,15 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   // slots cycle through the batches); measured: random_spheres 500 92.3 -> 88.3 ms, cornell_quads 16.5 -> 22.9 ms, so off
   // variant 4 (packetkernel.hip, one shading visit per bounce): triangle scenes with at most three lights and no Disney
   // material on an analytic primitive; anything else runs on variant 3
-  const bool usePacket = c->optVariant == 4 && hasTris && a.scene.nLights <= 3 && !a.scene.anyDisneyAnalytic;
+  // ("auto_packet", default on: variant 3 hands a SHORT launch -- fewer than 2e8 samples, e.g. one rank's share of a 4- or
+  // 8-way split of the benchmark frame -- to variant 4, whose paths have the shorter critical path: 74.6 against 78.4 ms for
+  // an 8-way share, but 499.6 against 491 ms for the whole frame)
+  const bool packetOk = hasTris && a.scene.nLights <= 3 && !a.scene.anyDisneyAnalytic;
+  const double nSamples = (double)a.nItems * (double)nSeeds;
+  const bool shortLaunch = nSamples < 2.0e8 && nSamples >= 1.0e6 && nSeeds >= 16;
+  const bool usePacket = packetOk && (c->optVariant == 4 || (!c->variantExplicit && c->optAutoPacket != 0 && shortLaunch));
   const bool useQueue = !usePacket && (c->optVariant >= 2) && (hasTris || c->optAnalyticQueue != 0);
+  c->lastVariant = usePacket ? 4 : useQueue ? (c->optVariant == 2 ? 2 : 3) : usePool ? 1 : 0;
   a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;
   a.slotsInUse = c->optSlotsInUse;     // resolved per pass below when -1
   a.watchdogTicks = (unsigned long long)c->optWatchdogMs * 100000ull;      // s_memrealtime counts at 100 MHz
@@ -597,7 +607,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   if (!strcmp(name, "exit_threshold")) { if (value < 0 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "exit_threshold in [0,64]"); c->optExitThreshold = value; }
   else if (!strcmp(name, "leaf_size")) { if (value < 1 || value > kMaxLeaf) return fail(c, MOPTIX_ERR_INVALID, "leaf_size in [1,8]"); if (value != c->optLeafSize) c->accelBuilt = false; c->optLeafSize = value; }
   else if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) return fail(c, MOPTIX_ERR_INVALID, "blocks_per_cu in [1,8]"); c->optBlocksPerCU = value; }
-  else if (!strcmp(name, "kernel_variant")) { if (value < 0 || value > 4) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {0,1,2,3,4}"); c->optVariant = value; }
+  else if (!strcmp(name, "kernel_variant")) { if (value < 0 || value > 4) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {0,1,2,3,4}"); c->optVariant = value; c->variantExplicit = true; }
   else if (!strcmp(name, "pool_slots")) { if (value != 128 && value != 192 && value != 256) return fail(c, MOPTIX_ERR_INVALID, "pool_slots in {128,192,256}"); c->optPoolSlots = value; }
   else if (!strcmp(name, "sample_buffer_mb")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "sample_buffer_mb >= 1"); c->optSampleBufMB = value; }
   else if (!strcmp(name, "leaf_threshold")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "leaf_threshold in [1,64]"); c->optLeafThreshold = value; }
@@ -605,6 +615,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "refill_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "refill_lanes in [1,64]"); c->optRefillLanes = value; }
   else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
   else if (!strcmp(name, "tile_major")) { if (value < 0 || value > 3) return fail(c, MOPTIX_ERR_INVALID, "tile_major in {0,1,2,3}"); c->optTileMajor = value; }
+  else if (!strcmp(name, "auto_packet")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "auto_packet in {0,1}"); c->optAutoPacket = value; }
   else if (!strcmp(name, "analytic_queue")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "analytic_queue in {0,1}"); c->optAnalyticQueue = value; }
   else if (!strcmp(name, "slots_in_use")) { if (value < -1 || value > 512) return fail(c, MOPTIX_ERR_INVALID, "slots_in_use in [-1,512]"); c->optSlotsInUse = value; }
   else if (!strcmp(name, "builder")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "builder in {0,1}"); if (value != c->optBuilder) c->accelBuilt = false; c->optBuilder = value; }
@@ -632,6 +643,8 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "builder")) *value = c->optBuilder;
   else if (!strcmp(name, "slots_in_use")) *value = c->optSlotsInUse;
   else if (!strcmp(name, "analytic_queue")) *value = c->optAnalyticQueue;
+  else if (!strcmp(name, "auto_packet")) *value = c->optAutoPacket;
+  else if (!strcmp(name, "kernel_variant_used")) *value = c->lastVariant;
   else if (!strcmp(name, "num_cus")) *value = c->numCUs;
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;

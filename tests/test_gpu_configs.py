@@ -320,3 +320,24 @@ def test_packet_variant_on_the_glass_and_million_triangle_scenes(gpu_ctx):
         assert np.array_equal(out[3][0], out[4][0]), kind
         for f in ("primaryRays", "bounceRays", "shadowRays", "closestHits", "lightLoads", "samples"):
             assert getattr(out[3][1], f) == getattr(out[4][1], f), (kind, f)
+
+
+def test_short_launches_pick_the_packet_kernel_by_themselves():
+    """A context whose kernel_variant was never set runs short launches (a rank's share of a multi-GPU frame) on
+    variant 4: same bits as an explicit variant 3, and auto_packet = 0 turns the choice off."""
+    ctx = M.Context(0)                                  # fresh context: kernel_variant untouched
+    try:
+        hs = M.HostScene("file:coffee", 1920, 1080)
+        seeds = M.launch_seeds(16)
+        ctx.set_partition(2, 8)                          # 259,200 pixels x 16 launches = 4.1e6 samples: "short"
+        ctx.load(hs)
+        auto, _ = _render(ctx, seeds)
+        assert ctx.get_option("kernel_variant_used") == 4
+        ctx.set_option("auto_packet", 0)
+        off, _ = _render(ctx, seeds)
+        assert ctx.get_option("kernel_variant_used") == 3
+        ctx.set_option("kernel_variant", 3)
+        v3, _ = _render(ctx, seeds)
+        assert np.array_equal(auto, v3) and np.array_equal(off, v3) and v3.any()
+    finally:
+        ctx.close()
