@@ -26,6 +26,7 @@ struct LaunchArgs {
   int swapLanes;                    // leave the node loop once this many lanes stand at a leaf / have finished
   int ovfDepth;                     // ints of stack overflow per slot
   int slotsInUse;                   // path slots per pool a launch uses (0 = all); fewer slots = shorter critical path
+  int auxDepth;                     // variant 4: paths this deep trace their shadow rays in borrowed slots, beside the continuation (0 = off)
   unsigned long long watchdogTicks; // a wave gives up after this many 100 MHz ticks (sets workCounter[1]; the pass is then not reduced)
   // hand-out order of the work items (queuekernel.hip): tile-major, tiles with the deepest paths first
   int tileMajor;                    // 0 = sample-major in raster tile order (item k handed out as k); 1, 2 = by tile; 3 = by pixel

@@ -87,6 +87,7 @@ struct moptix_context_t {
   int lastVariant = -1;              // what the last render ran (get_option "kernel_variant_used")
   bool variantExplicit = false;      // kernel_variant was set by the caller: no automatic choice
   int optSlotsInUse = -1;            // -1 = chosen per launch from its size
+  int optAuxDepth = 16;              // variant 4: depth from which a path's shadow rays get slots of their own (0 = off)
   double kernelMs = 0.0, reduceMs = 0.0; uint64_t nLaunches = 0;
   bool asyncPending = false;
 };
@@ -216,8 +217,8 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   // variant 4 (packetkernel.hip, one shading visit per bounce): triangle scenes with at most three lights and no Disney
   // material on an analytic primitive; anything else runs on variant 3
   // ("auto_packet", default on: variant 3 hands a SHORT launch -- fewer than 2e8 samples, e.g. one rank's share of a 4- or
-  // 8-way split of the benchmark frame -- to variant 4, whose paths have the shorter critical path: 74.6 against 78.4 ms for
-  // an 8-way share, but 499.6 against 491 ms for the whole frame)
+  // 8-way split of the benchmark frame -- to variant 4, whose paths have the shorter critical path: 66.7 against 78.4 ms for
+  // an 8-way share, 125.0 against 127.6 ms for a 4-way share; 492.8 against 492 ms for the whole frame)
   const bool packetOk = hasTris && a.scene.nLights <= 3 && !a.scene.anyDisneyAnalytic;
   const double nSamples = (double)a.nItems * (double)nSeeds;
   const bool shortLaunch = nSamples < 2.0e8 && nSamples >= 1.0e6 && nSeeds >= 16;
@@ -225,7 +226,12 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   const bool useQueue = !usePacket && (c->optVariant >= 2) && (hasTris || c->optAnalyticQueue != 0);
   c->lastVariant = usePacket ? 4 : useQueue ? (c->optVariant == 2 ? 2 : 3) : usePool ? 1 : 0;
   a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;
-  a.slotsInUse = c->optSlotsInUse;     // resolved per pass below when -1
+  // Slots without a path are what deep paths borrow for their shadow rays (packetkernel.hip, "aux_depth"); once the work
+  // items run out there are plenty, before that only the ones kept free here.  A launch under 1e8 samples (an 8-way share
+  // of the benchmark frame) is short enough for its tail to matter more than the throughput of 64 more paths per pool:
+  // 66.7 ms with 448 of 512 slots in use against 70.1 ms with all of them; a 4-way share: 130.3 against 125.0 ms.
+  a.slotsInUse = c->optSlotsInUse >= 0 ? c->optSlotsInUse : (usePacket && c->optAuxDepth > 0 && nSamples < 1.0e8 ? 448 : 0);
+  a.auxDepth = usePacket ? c->optAuxDepth : 0;
   a.watchdogTicks = (unsigned long long)c->optWatchdogMs * 100000ull;      // s_memrealtime counts at 100 MHz
   if (usePacket) {
     a.ovfDepth = std::max(0, c->bvh.stackBound - packetkernel_lds_stack_entries() + 1);
@@ -617,6 +623,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "tile_major")) { if (value < 0 || value > 3) return fail(c, MOPTIX_ERR_INVALID, "tile_major in {0,1,2,3}"); c->optTileMajor = value; }
   else if (!strcmp(name, "auto_packet")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "auto_packet in {0,1}"); c->optAutoPacket = value; }
   else if (!strcmp(name, "analytic_queue")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "analytic_queue in {0,1}"); c->optAnalyticQueue = value; }
+  else if (!strcmp(name, "aux_depth")) { if (value < 0 || value > 100000) return fail(c, MOPTIX_ERR_INVALID, "aux_depth in [0,100000]"); c->optAuxDepth = value; }
   else if (!strcmp(name, "slots_in_use")) { if (value < -1 || value > 512) return fail(c, MOPTIX_ERR_INVALID, "slots_in_use in [-1,512]"); c->optSlotsInUse = value; }
   else if (!strcmp(name, "builder")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "builder in {0,1}"); if (value != c->optBuilder) c->accelBuilt = false; c->optBuilder = value; }
   else if (!strcmp(name, "fast_shading")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "fast_shading in {0,1}"); c->optFastShading = value; }
@@ -641,6 +648,7 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "watchdog_ms")) *value = c->optWatchdogMs;
   else if (!strcmp(name, "fast_shading")) *value = c->optFastShading;
   else if (!strcmp(name, "builder")) *value = c->optBuilder;
+  else if (!strcmp(name, "aux_depth")) *value = c->optAuxDepth;
   else if (!strcmp(name, "slots_in_use")) *value = c->optSlotsInUse;
   else if (!strcmp(name, "analytic_queue")) *value = c->optAnalyticQueue;
   else if (!strcmp(name, "auto_packet")) *value = c->optAutoPacket;

@@ -102,6 +102,12 @@ struct PoolLds {
   unsigned short queue[kNumQ][ring_capacity(NS)];
   int qHead[kNumQ], qCount[kNumQ];   // SHARED only
   int done, lock;                    // SHARED only
+  // Concurrent shadow rays for deep paths (LaunchArgs::auxDepth): a slot whose path is done (the work items ran out, or
+  // LaunchArgs::slotsInUse left it without one) can be borrowed by a deep path, one per shadow ray of a hit, so that
+  // the shadow rays and the continuation are traced at the same time: the launch's tail is a few capped paths walking
+  // their 257 bounces, and this divides the time each bounce takes.
+  unsigned int freeMask[NS / 32];    // bit set: the slot carries no path and nobody has borrowed it
+  int nFree;                         // set bits in freeMask (approximate: read without the lock)
 };
 
 template <int NS>
@@ -126,6 +132,18 @@ constexpr int kCurShift = 8;          // bits 8-9: index of the ray in flight wi
 constexpr int kNShShift = 10;         // bits 10-11: shadow rays in the packet
 constexpr int kNRayShift = 12;        // bits 12-13: rays in the packet - 1
 constexpr int kStatShift = 14;        // bits 14-19: per shadow ray 0 = attenuation (1,1,1), 1 = (0,0,0), 2 = tinted (att row)
+constexpr int kHasAux = 1 << 21;      // path slot: the packet's shadow rays are being traced by borrowed slots (join before shading)
+constexpr int kAuxSlot = 1 << 22;     // borrowed slot: one shadow ray of the path slot named in bits 16-20 and 23-26 (aux_parent)
+constexpr int kPendShift = 23;        // bits 23-24: pend rows the next visit has to read (= the packet's shadow rays, wherever they are traced)
+// Join of a path slot with its borrowed slots, in the path slot's flag word: only these bits are touched by other
+// waves (LDS atomics), so the owner updates the rest of the word with atomics too while kHasAux is set (store_flags).
+constexpr int kJoinShift = 25;        // bits 25-26: borrowed slots whose shadow ray is still out
+constexpr int kArrived = 1 << 27;     // the path slot's own ray is done (or it had none)
+constexpr int kJoinMask = (3 << kJoinShift) | kArrived;
+__device__ __forceinline__ int aux_parent_bits(int parent) { return ((parent & 31) << 16) | ((parent >> 5) << 23); }
+__device__ __forceinline__ int aux_parent(int fl) { return ((fl >> 16) & 31) | (((fl >> 23) & 15) << 5); }
+// SlotCold::ctl.w bit 7: the path holds three borrowed slots (9 bits each in thr.w), kept until the path ends
+constexpr int kCtlHoldsAux = 1 << 7;
 constexpr int kHasScale = 1 << 20;    // SlotCold::bsc holds the continuation's weight (a Disney bounce)
 constexpr int kSwitchRef = (int)0x80000000;   // "node" of a slot whose ray ended while another ray of the packet is pending
 __device__ __forceinline__ int fl_cur(int fl) { return (fl >> kCurShift) & 3; }
@@ -165,12 +183,20 @@ __device__ __forceinline__ int route(int node, int kind, int bestPrim) {
   return node >= 0 ? Q_NODE : Q_LEAF;
 }
 
-// pt_packet.h's sink for the shadow rays of a new packet: see run_batch
+// pt_packet.h's sink for the shadow rays of a new packet: each goes to the slot as soon as it is known (weight row; the ray
+// itself to LDS if it is the first of the list, else to its ray row) -- or, for a deep path that has borrowed slots, each
+// shadow ray goes to its own borrowed slot, to be traced at the same time as the continuation.
 struct SlotSink {
-  SlotCold* cw; v4* nodeA; v4* nodeB; const PathState* ps; int root;
+  SlotCold* cold; int slot; v4* nodeA; v4* nodeB; int (*stack)[kStackN + 1]; const PathState* ps; int root;
+  int axp;                              // this path's three borrowed slots (9 bits each) or -1
   __device__ __forceinline__ void shadow(int j, v3 d, float tmax, v3 w, float inv) const {
+    SlotCold* cw = cold + slot;
     slot_store(&cw->pend[j], mk4(w.x, w.y, w.z, inv));
-    if (j == 0) { *nodeA = mk4(ps->o.x, ps->o.y, ps->o.z, tmax); *nodeB = mk4(d.x, d.y, d.z, i2f(root)); }   // ps->o: the hit point
+    if (axp >= 0) {
+      const int ax = (axp >> (9 * j)) & 511;
+      nodeA[ax] = mk4(ps->o.x, ps->o.y, ps->o.z, tmax); nodeB[ax] = mk4(d.x, d.y, d.z, i2f(root));
+      stack[ax][0] = kAuxSlot | kShadowRay | kShadeFlag | (1 << kNShShift) | aux_parent_bits(slot);      // a packet of one shadow ray
+    } else if (j == 0) { nodeA[slot] = mk4(ps->o.x, ps->o.y, ps->o.z, tmax); nodeB[slot] = mk4(d.x, d.y, d.z, i2f(root)); }   // ps->o: the hit point
     else slot_store(&cw->ray[j - 1], mk4(d.x, d.y, d.z, tmax));
   }
 };
@@ -242,13 +268,40 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     return st;
   };
 
+  // Flag word of a slot after a traversal step.  While the slot's shadow rays are out in borrowed slots, other waves
+  // count down in the join bits of the word: the owner then leaves those bits alone.
+  auto store_flags = [&](int slot, int value) {
+    if (__builtin_expect((value & kHasAux) != 0, 0)) { atomicAnd(&W.stack[slot][0], kJoinMask); atomicOr(&W.stack[slot][0], value & ~kJoinMask); }
+    else W.stack[slot][0] = value;
+  };
+  // The path slot's own ray is done.  True = some shadow rays are still out: the slot parks (in no queue) and the last
+  // of them pushes it to Q_SHADE.
+  auto arrive_parks = [&](int slot) -> bool {
+    const int old = atomicOr(&W.stack[slot][0], kArrived);
+    return ((old >> kJoinShift) & 3) != 0;
+  };
+  // A borrowed slot's shadow ray is done (its attenuation is in its flag word / att row, read by the path slot's next
+  // visit).  Returns the path slot if this was the last one out and the path slot's own ray is done as well (the caller
+  // pushes it to Q_SHADE), else -1.
+  auto aux_done = [&](int fl) -> int {
+    const int parent = aux_parent(fl);
+    const int old = atomicSub(&W.stack[parent][0], 1 << kJoinShift);
+    return (old & kJoinMask) == ((1 << kJoinShift) | kArrived) ? parent : -1;
+  };
+
   // ---- start-up: every slot in use needs a work item ----
   // Paths in flight = slots in use; by Little's law a ray spends (slots in use) / (rays per second) in the scheduler,
   // about 70 us with all 512 slots of every pool, so a path that bounces to the depth cap (about 1000 dependent rays)
   // takes 70-90 ms however short the launch is.  A short launch (one rank's share of a multi-GPU frame) therefore
   // uses fewer slots: a little less throughput, a much shorter critical path (LaunchArgs::slotsInUse, moptix_api.hip).
+  const bool auxOn = SHARED && a.auxDepth > 0 && sc.rootRef >= 0;
   const int nUse = (a.slotsInUse > 0 && a.slotsInUse < NS) ? (SHARED ? a.slotsInUse : max(64, a.slotsInUse / kWaves)) : NS;
   {
+    if (SHARED && threadIdx.x < NS / 32) {      // slots without a path can be borrowed from the start
+      const int lo = (int)threadIdx.x * 32;
+      W.freeMask[threadIdx.x] = !auxOn || nUse >= lo + 32 ? 0u : (nUse <= lo ? ~0u : ~0u << (nUse - lo));
+    }
+    if (threadIdx.x == 0) W.nFree = auxOn ? NS - nUse : 0;
     const int first = SHARED ? threadIdx.x : lane, step = SHARED ? kBlockThreads : 64;
     for (int s = first; s < nUse; s += step) {
       i4 ctl; ctl.x = -1; ctl.y = 0; ctl.z = 0; ctl.w = M_NEW_PIXEL;     // item -1: whatever sample comes first is "new" (rows get written)
@@ -288,6 +341,40 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
 
   // result of the last pass, queued inside the next transaction
   int pendSlot = -1, pendDest = DEST_NONE;
+
+  // per-wave private structures: the node-ready ring (slots produced by this wave's own passes
+  // stay with the wave) and the out-boxes that collect slots for the pool-wide queues between
+  // two transactions
+  unsigned short* myNodeQ = sPriv[wave].qnode;
+  int nqHead = 0, nqCount = 0;
+  unsigned short* myLeafQ = sPriv[wave].qleaf;
+  int lqHead = 0, lqCount = 0;             // leaf-ready ring: leaf passes need no queue transaction
+  int obCount[2] = { 0, 0 };               // out-boxes for Q_SHADE, Q_GEN
+  int localDone = 0;
+  auto local_push = [&](int dest, int slot) {   // wave-collective; dest per lane
+    {
+      const unsigned long long m = __ballot(dest == Q_NODE);
+      if (m != 0ull) {
+        if (dest == Q_NODE) myNodeQ[(nqHead + nqCount + lane_rank(m)) & (RC - 1)] = (unsigned short)slot;
+        nqCount += __popcll(m);
+      }
+    }
+    {
+      const unsigned long long m = __ballot(dest == Q_LEAF);
+      if (m != 0ull) {
+        if (dest == Q_LEAF) myLeafQ[(lqHead + lqCount + lane_rank(m)) & 255] = (unsigned short)slot;
+        lqCount += __popcll(m);
+      }
+    }
+    for (int d = 0; d < 2; d++) {
+      const unsigned long long m = __ballot(dest == Q_SHADE + d);
+      if (m != 0ull) {
+        if (dest == Q_SHADE + d) sPriv[wave].outbox[d][obCount[d] + lane_rank(m)] = (unsigned short)slot;
+        obCount[d] += __popcll(m);
+      }
+    }
+    localDone += __popcll(__ballot(dest == DEST_DONE));
+  };
 
   // ---- leaf pass: the slots popped from Q_LEAF stand at a leaf ----
   auto leaf_pass = [&](int slot) {
@@ -359,8 +446,14 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         } else {
           W.nodeA[slot].w = tv.tbest;
           W.nodeB[slot].w = i2f(tv.node);
-          W.stack[slot][0] = tv.sp | nfl;
+          store_flags(slot, tv.sp | nfl);
           pendDest = tv.node == kTravDone ? ((nfl & kShadeFlag) ? Q_SHADE : Q_GEN) : (tv.node >= 0 ? Q_NODE : Q_LEAF);
+          if (__builtin_expect(tv.node == kTravDone && (nfl & (kHasAux | kAuxSlot)) != 0, 0)) {      // rare: deep paths only
+            if (nfl & kAuxSlot) {
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the att row written above is read by the path slot's visit
+              pendSlot = aux_done(nfl); pendDest = pendSlot >= 0 ? Q_SHADE : DEST_NONE;
+            } else if (arrive_parks(slot)) pendDest = DEST_NONE;
+          }
         }
       }
     }
@@ -385,15 +478,18 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     Packet pk; packet_clear(pk);
     v3 att[kPacketShadows] = { mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f) };
+    int axp = -1;                                      // the three slots this path has borrowed for its shadow rays (9 bits each), -1 = none
     if (have) {
       const SlotCold* cs = cold + slot;
       const int fl = W.stack[slot][0];
       const bool hitValid = (fl & kHitValid) != 0;
-      const int nSh = fl_nsh(fl);                      // 0 for a slot that waits for a work item (flags are cleared then)
+      const int nSh = (fl >> kPendShift) & 3;          // 0 for a slot that waits for a work item (flags are cleared then)
+      const bool hadAux = (fl & kHasAux) != 0;         // its shadow rays were traced by the borrowed slots
       const i4 ctl = slot_load(&cs->ctl);
       const v4 thrIn = slot_load(&cs->thr), radIn = slot_load(&cs->rad);
       v4 wh = mk4(0.f, 0.f, 0.f, 0.f), wb = mk4(1.f, 1.f, 1.f, 1.f);
       v4 wp[kPacketShadows], wa[kPacketShadows];
+      if (ctl.w & kCtlHoldsAux) axp = f2i(thrIn.w);
       if (hitValid) wh = slot_load(&cs->hit);
       if (fl & kHasScale) wb = slot_load(&cs->bsc);
 #pragma unroll
@@ -401,8 +497,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         wp[i] = mk4(0.f, 0.f, 0.f, 0.f); wa[i] = mk4(1.f, 1.f, 1.f, 0.f);
         if (i < nSh) {
           wp[i] = slot_load(&cs->pend[i]);
-          const int stt = fl_stat(fl, i);
-          if (stt == 2) wa[i] = slot_load(&cs->att[i]);
+          const int ax = (axp >> (9 * i)) & 511;                 // only used with hadAux
+          const int stt = hadAux ? fl_stat(W.stack[ax][0], 0) : fl_stat(fl, i);
+          if (stt == 2) wa[i] = hadAux ? slot_load(&cold[ax].att[0]) : slot_load(&cs->att[i]);
           else if (stt == 1) wa[i] = mk4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -422,6 +519,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       if (hitValid) { res.bestTri = f2i(wh.x); res.bestPrim = f2i(wh.y); res.beta = wh.z; res.gamma = wh.w; }
       if (ps.mode == M_TRACE) ps.mode = M_RESULT;
     }
+    const SlotSink sink{ cold, slot >= 0 ? slot : 0, W.nodeA, W.nodeB, W.stack, &ps, sc.rootRef, axp };
     if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBLoad); }
     for (;;) {
       if (have && ps.mode == M_NEW_SAMPLE) {
@@ -445,9 +543,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       }
       if (run) {
         if (ps.mode == M_RESULT) {
-          // a new packet's shadow rays go straight to the slot (SlotSink): weight row, and the ray itself to LDS (the
-          // first one) or to its ray row -- not held in registers across the BRDF evaluations of the lights that follow
-          on_result_packet<CNT, FAST, SlotSink>(sc, ps, pk, res, att, ct, SlotSink{ cold + slot, &W.nodeA[slot], &W.nodeB[slot], &ps, sc.rootRef });
+          on_result_packet<CNT, FAST, SlotSink>(sc, ps, pk, res, att, ct, sink);
         } else {  // M_NEW_PIXEL: next (pixel, sample) work item
           int k = atomicAdd(a.workCounter, 1);
           k = (k >= a.nWork) ? -1 : handout_to_item(a, k);
@@ -459,12 +555,39 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       }
     }
     if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBRun); }
+    bool useAux = false;
     if (have) {
       SlotCold* cw = cold + slot;
+      // borrowed slots go back when the path has ended (the lane may hold a new path's camera ray by now)
+      if (axp >= 0 && !(ps.mode == M_TRACE && ps.depth >= a.auxDepth)) {
+        for (int j = 0; j < kPacketShadows; j++) { const int ax = (axp >> (9 * j)) & 511; atomicOr(&W.freeMask[ax >> 5], 1u << (ax & 31)); }
+        atomicAdd(&W.nFree, kPacketShadows);
+        axp = -1;
+      }
+      // a path that gets deep borrows three slots (one per possible shadow ray of a hit; used from its next hit on)
+      int axpNext = axp;
+      if (auxOn) {
+        const bool wantAux = axp < 0 && ps.mode == M_TRACE && ps.depth >= a.auxDepth;
+        if (wantAux && W.nFree >= kPacketShadows) {                // rare: lanes take their turn at the free list (LDS atomics)
+          int got = 0, pack = 0;
+          for (int wi = 0; wi < NS / 32 && got < kPacketShadows; wi++) {
+            unsigned int cur = W.freeMask[wi];
+            while (cur != 0u && got < kPacketShadows) {
+              const int b = __builtin_ctz(cur);
+              const unsigned int prev = atomicAnd(&W.freeMask[wi], ~(1u << b));       // claims the bit if it is still there
+              if (prev & (1u << b)) { pack |= (wi * 32 + b) << (9 * got); got++; }
+              cur = prev & ~(1u << b);
+            }
+          }
+          if (got == kPacketShadows) { axpNext = pack; atomicSub(&W.nFree, kPacketShadows); }
+          else for (int j = 0; j < got; j++) { const int ax = (pack >> (9 * j)) & 511; atomicOr(&W.freeMask[ax >> 5], 1u << (ax & 31)); }
+        }
+      }
       i4 ctl; ctl.x = ps.item; ctl.y = ps.depth; ctl.z = (int)ps.seed;
       ctl.w = ps.mode | (pk.nShadow << 3) | (pk.hasBounce << 5) | (pk.hasScale << 6);
+      if (axpNext >= 0) ctl.w |= kCtlHoldsAux;
       slot_store(&cw->ctl, ctl);
-      slot_store(&cw->thr, mk4(ps.thr.x, ps.thr.y, ps.thr.z, 0.f));
+      slot_store(&cw->thr, mk4(ps.thr.x, ps.thr.y, ps.thr.z, i2f(axpNext)));
       slot_store(&cw->rad, mk4(ps.rad.x, ps.rad.y, ps.rad.z, 0.f));
       if (ps.mode == M_TRACE) {
         // new packet: the brute-force lists for the continuation (radiance) ray, then the rays in trace order: shadow rays
@@ -478,9 +601,11 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         }
         const bool hitNow = bp0 >= 0;
         if (hitNow) slot_store(&cw->hit, mk4(i2f(-1), i2f(bp0), 0.f, 0.f));
-        const int nRays = pk.nShadow + pk.hasBounce;
+        useAux = axp >= 0 && pk.nShadow > 0;               // the shadow rays sit in the borrowed slots (SlotSink)
+        const int nOwnSh = useAux ? 0 : pk.nShadow;
+        const int nRays = nOwnSh + pk.hasBounce;
         const v4 rb = mk4(ps.d.x, ps.d.y, ps.d.z, tb0);                                     // the continuation: last ray of the list
-        if (pk.nShadow == 0) {                                                              // ... and the first one here
+        if (nOwnSh == 0) {                                                                  // ... and the first one here
           W.nodeA[slot] = mk4(ps.o.x, ps.o.y, ps.o.z, rb.w);
           W.nodeB[slot] = mk4(rb.x, rb.y, rb.z, i2f(sc.rootRef));
         } else if (pk.hasBounce) {
@@ -490,50 +615,28 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           else slot_store(&cw->ray[2], rb);
         }
         if (pk.hasScale) slot_store(&cw->bsc, mk4(pk.bscale.x, pk.bscale.y, pk.bscale.z, pk.binv));
-        W.stack[slot][0] = (pk.nShadow << kNShShift) | ((nRays - 1) << kNRayShift) | (pk.nShadow > 0 ? kShadowRay : 0) |
-                           (hitNow ? kHitValid : 0) | ((pk.nShadow > 0 || hitNow) ? kShadeFlag : 0) | (pk.hasScale ? kHasScale : 0);
+        W.stack[slot][0] = (nOwnSh << kNShShift) | ((max(nRays, 1) - 1) << kNRayShift) | (nOwnSh > 0 ? kShadowRay : 0) | (pk.nShadow << kPendShift) |
+                           (hitNow ? kHitValid : 0) | ((pk.nShadow > 0 || hitNow) ? kShadeFlag : 0) | (pk.hasScale ? kHasScale : 0) |
+                           (useAux ? kHasAux : 0);
         pendDest = sc.rootRef >= 0 ? Q_NODE : Q_LEAF;
+        if (useAux) {
+          // join bits: shadow rays out; a packet without a continuation has nothing of its own to trace and parks at once
+          W.stack[slot][0] |= (pk.nShadow << kJoinShift) | (pk.hasBounce ? 0 : kArrived);
+          if (!pk.hasBounce) pendDest = DEST_NONE;
+        }
       } else {
         W.stack[slot][0] = 0;
         pendDest = (ps.mode == M_NEW_PIXEL) ? Q_GEN : DEST_DONE;
+        if (auxOn && ps.mode != M_NEW_PIXEL) {               // no work item left for this slot: deep paths may borrow it
+          atomicOr(&W.freeMask[slot >> 5], 1u << (slot & 31)); atomicAdd(&W.nFree, 1);
+        }
       }
+    }
+    if (auxOn && __ballot(useAux) != 0ull) {                // the borrowed slots start at the root, with this wave
+      for (int j = 0; j < kPacketShadows; j++) local_push((useAux && j < pk.nShadow) ? Q_NODE : DEST_NONE, (axp >> (9 * j)) & 511);
     }
     if constexpr (!SHARED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     PT_SUB(tBStore);
-  };
-
-  // per-wave private structures: the node-ready ring (slots produced by this wave's own passes
-  // stay with the wave) and the out-boxes that collect slots for the pool-wide queues between
-  // two transactions
-  unsigned short* myNodeQ = sPriv[wave].qnode;
-  int nqHead = 0, nqCount = 0;
-  unsigned short* myLeafQ = sPriv[wave].qleaf;
-  int lqHead = 0, lqCount = 0;             // leaf-ready ring: leaf passes need no queue transaction
-  int obCount[2] = { 0, 0 };               // out-boxes for Q_SHADE, Q_GEN
-  int localDone = 0;
-  auto local_push = [&](int dest, int slot) {   // wave-collective; dest per lane
-    {
-      const unsigned long long m = __ballot(dest == Q_NODE);
-      if (m != 0ull) {
-        if (dest == Q_NODE) myNodeQ[(nqHead + nqCount + lane_rank(m)) & (RC - 1)] = (unsigned short)slot;
-        nqCount += __popcll(m);
-      }
-    }
-    {
-      const unsigned long long m = __ballot(dest == Q_LEAF);
-      if (m != 0ull) {
-        if (dest == Q_LEAF) myLeafQ[(lqHead + lqCount + lane_rank(m)) & 255] = (unsigned short)slot;
-        lqCount += __popcll(m);
-      }
-    }
-    for (int d = 0; d < 2; d++) {
-      const unsigned long long m = __ballot(dest == Q_SHADE + d);
-      if (m != 0ull) {
-        if (dest == Q_SHADE + d) sPriv[wave].outbox[d][obCount[d] + lane_rank(m)] = (unsigned short)slot;
-        obCount[d] += __popcll(m);
-      }
-    }
-    localDone += __popcll(__ballot(dest == DEST_DONE));
   };
 
   unsigned int guard = 0;
@@ -547,13 +650,19 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     {
       const bool leave = ns >= 0 && !(ntv.node >= 0 && ntv.node != kTravDone);
       if (__ballot(leave) != 0ull) {
-        int dest = DEST_NONE;
+        int dest = DEST_NONE, pushSlot = ns;
         if (leave) {
           const int nodeOut = (ntv.node == kTravDone && fl_more(nsFlag)) ? kSwitchRef : ntv.node;   // ray done, packet not: the leaf pass switches rays
-          W.nodeB[ns].w = i2f(nodeOut); W.stack[ns][0] = ntv.sp | nsFlag;
+          W.nodeB[ns].w = i2f(nodeOut); store_flags(ns, ntv.sp | nsFlag);
           dest = (nodeOut == kTravDone) ? ((nsFlag & kShadeFlag) ? Q_SHADE : Q_GEN) : Q_LEAF;   // a lane leaves at a leaf, at a ray switch or finished
+          if (__builtin_expect(nodeOut == kTravDone && (nsFlag & (kHasAux | kAuxSlot)) != 0, 0)) {     // rare: deep paths only
+            if (nsFlag & kAuxSlot) {
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // att rows written by this wave's last leaf pass
+              pushSlot = aux_done(nsFlag); dest = pushSlot >= 0 ? Q_SHADE : DEST_NONE;
+            } else if (arrive_parks(ns)) dest = DEST_NONE;
+          }
         }
-        local_push(dest, ns);
+        local_push(dest, pushSlot);
         if (leave) ns = -1;
       }
       if (nqCount > 0 && __ballot(ns < 0) != 0ull) {

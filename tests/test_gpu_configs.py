@@ -322,6 +322,35 @@ def test_packet_variant_on_the_glass_and_million_triangle_scenes(gpu_ctx):
             assert getattr(out[3][1], f) == getattr(out[4][1], f), (kind, f)
 
 
+def test_borrowed_slots_for_deep_paths_shadow_rays_change_nothing(gpu_ctx):
+    """Variant 4 traces a deep path's shadow rays in slots borrowed from finished paths, beside the continuation
+    (option aux_depth; slots_in_use decides how many are free from the start).  Scheduling only: same bits and the same
+    counters as variant 3 whether every hit borrows (aux_depth 1), only the deep ones, or none, with slots free from the
+    start or only in the launch's tail, and in the counting build."""
+    for kind, kw, res, spp in (("file:coffee", {}, (320, 180), 3), ("coffee_pot_standin", {}, (200, 112), 2),
+                               ("million_standin", dict(iarg=50000), (160, 90), 2), ("dining_standin", dict(iarg=2), (160, 90), 2)):
+        hs = M.HostScene(kind, res[0], res[1], **kw)
+        seeds = M.launch_seeds(spp)
+        try:
+            gpu_ctx.set_option("kernel_variant", 3)
+            gpu_ctx.load(hs)
+            ref, rst = _render(gpu_ctx, seeds, counted=True)
+            gpu_ctx.set_option("kernel_variant", 4)
+            for aux_depth, slots, counted in ((1, -1, True), (1, 256, False), (2, 448, True), (5, 64, False), (16, 448, False), (0, -1, False)):
+                gpu_ctx.set_option("aux_depth", aux_depth)
+                gpu_ctx.set_option("slots_in_use", slots)
+                gpu_ctx.load(hs)
+                got, st = _render(gpu_ctx, seeds, counted=counted)
+                assert np.array_equal(ref, got), (kind, aux_depth, slots)
+                if counted:
+                    for f in ("primaryRays", "bounceRays", "shadowRays", "closestHits", "lightLoads", "samples"):
+                        assert getattr(rst, f) == getattr(st, f), (kind, aux_depth, slots, f)
+        finally:
+            gpu_ctx.set_option("kernel_variant", 3)
+            gpu_ctx.set_option("aux_depth", 16)
+            gpu_ctx.set_option("slots_in_use", -1)
+
+
 def test_short_launches_pick_the_packet_kernel_by_themselves():
     """A context whose kernel_variant was never set runs short launches (a rank's share of a multi-GPU frame) on
     variant 4: same bits as an explicit variant 3, and auto_packet = 0 turns the choice off."""

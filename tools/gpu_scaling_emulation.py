@@ -9,6 +9,10 @@ W, H = 1920, 1080
 spp = int(os.environ.get("SPP", "256"))
 hs = M.HostScene("file:coffee", W, H)
 seeds = M.launch_seeds(spp)
+for o in os.environ.get("OPTS", "").split(","):
+    if "=" in o:
+        k, v = o.split("="); ctx.set_option(k, int(v))
+NS = [int(x) for x in os.environ.get("NS", "2,4,8").split(",")]
 def timed():
     best = 1e9
     for rep in range(3):
@@ -16,7 +20,7 @@ def timed():
     return best
 ctx.load(hs); t1 = timed()
 print("N=1: %.1f ms" % t1, flush=True)
-for n in (2, 4, 8):
+for n in NS:
     ts = []
     for r in range(n):
         ctx.set_partition(r, n); ctx.load(hs); ts.append(timed())
