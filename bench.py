@@ -242,7 +242,7 @@ def main():
         elif sample_split:
             par = "sample-split x%d (rank r renders launches i = r mod %d) + RCCL reduce" % (world, world)
         else:
-            par = "tile-split x%d (8x8 tiles dealt round-robin) + RCCL gather" % world
+            par = "tile-split x%d (8x8 tiles dealt round-robin, rotating per group) + RCCL gather" % world
         if pipeline:
             par += ", two frames in flight"
         traffic = read_traffic(REPO) if (world == 1 and emu <= 1 and a.scene == "file:coffee" and (W, H, a.spp) == (1920, 1080, 256)) else None

@@ -175,19 +175,22 @@ int moptix_sync(moptix_context ctx);
 /* same work with the in-kernel counters enabled (slower; not for timing) */
 int moptix_render_counted(moptix_context ctx, const int32_t* seeds, int32_t nSeeds, moptix_stats* out);
 
-/* Multi-GPU tile split (new): this context renders only the 8x8-pixel
- * tiles t (raster order) with t % nRanks == rank.  Default (0,1) = whole frame. */
+/* Multi-GPU tile split (new): this context renders one 8x8-pixel tile of every
+ * group of nRanks tiles (raster order): tile g * nRanks + (rank + g) % nRanks of group g (the deal
+ * rotates from group to group so that no rank owns whole columns).  Default (0,1) = whole frame. */
 int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
 
 /* tuning knobs (none of them changes a bit of the image):
- *   "kernel_variant"   0 = one path per lane, 1 = per-wave path pool, 2 = per-wave stage queues,
- *                      3 = workgroup-shared stage queues (default; scenes without triangles always use 0)
- *   "kernel_variant"   0 per-lane kernel, 1 per-wave pool, 2 slot queues per wave, 3 slot queues per workgroup (default),
+ *   "kernel_variant"   0 per-lane kernel (scenes without triangles always use it), 1 per-wave pool, 2 slot queues per wave, 3 slot queues per workgroup (default),
  *                      4 = 3 with one shading visit per bounce (pt_packet.h; scenes with <= 3 lights, else 3 runs).
  *                      While it has not been set, a short launch (1e6..2e8 samples, >= 16 seeds: one rank's share of a
  *                      multi-GPU frame) runs on 4 ("auto_packet" = 0 turns that off): shorter critical path per path
  *   "builder"          1 binned-SAH topology over the Morton order (default), 0 Morton radix tree
- *   "slots_in_use", "analytic_queue"   scheduling experiments, see DESIGN.md
+ *   "slots_in_use"     path slots per 512-slot pool that carry a path (-1 = chosen per launch: 448 for variant 4 launches
+ *                      under 1e8 samples, else all); the others are what deep paths borrow, see "aux_depth"
+ *   "aux_depth"        variant 4: a path this deep (default 16; 0 = never) traces the shadow rays of each hit in slots
+ *                      borrowed from finished paths, at the same time as the continuation ray (DESIGN.md "Borrowed slots")
+ *   "analytic_queue"   scheduling experiment, see DESIGN.md
  *   "leaf_size"        1..8 triangles per BVH leaf (default 4; takes effect at the next build_accel)
  *   "tile_major"       hand-out order of the (pixel, sample) work items: 0 = sample-major, 1 = all samples of an
  *                      8x8 tile back to back, tiles with the deepest paths of earlier launches first (default),

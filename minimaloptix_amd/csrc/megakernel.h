@@ -38,13 +38,16 @@ constexpr int kDeepPath = 8;        // paths at least this deep are recorded in 
 
 #if defined(__HIPCC__)
 // work item k -> (sample index, pixel).  Slot i = k % nItems is the (i & 63)-th pixel of this
-// rank's (i >> 6)-th 8x8 tile; tiles are dealt round-robin to the ranks in raster order
-// (tile-interleaved multi-GPU partition).  False for pixels outside the frame.
+// rank's (i >> 6)-th 8x8 tile.  Tiles are dealt to the ranks in raster order, nRanks at a time, and the deal
+// rotates by one rank from each group of nRanks tiles to the next (tile-interleaved multi-GPU partition,
+// SURVEY 8e): a plain t % nRanks gives every rank the same columns in every row when nRanks divides the
+// tiles of a row (1920 / 8 = 240 tiles, 8 ranks), and the ranks' ray counts then differ by 3-4 %.
+// False for pixels outside the frame (this includes the tiles past the end of a rank's last group).
 __device__ __forceinline__ bool item_to_pixel(const LaunchArgs& a, int k, int& sample, int& pixel) {
   sample = k / a.nItems;
   const int i = k - sample * a.nItems;
   const int lt = i >> 6, in = i & 63;
-  const int gt = lt * a.nRanks + a.rank;
+  const int gt = lt * a.nRanks + (a.rank + lt) % a.nRanks;
   const int tx = gt % a.tilesX, ty = gt / a.tilesX;
   const int x = tx * 8 + (in & 7), y = ty * 8 + (in >> 3);
   pixel = y * a.scene.width + x;

@@ -195,7 +195,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   a.accum = accum_ptr(c);
   const int tilesX = ((int)c->params.width + 7) / 8, tilesY = ((int)c->params.height + 7) / 8;
   const long long nTiles = (long long)tilesX * tilesY;
-  const long long localTiles = (nTiles - c->rank + c->nRanks - 1) / c->nRanks;
+  const long long localTiles = (nTiles + c->nRanks - 1) / c->nRanks;     // one tile of every group of nRanks (megakernel.h item_to_pixel)
   if (localTiles * 64 > 0x7fffffffLL) return fail(c, MOPTIX_ERR_LIMIT, "frame too large");
   a.nItems = (int)(localTiles * 64); a.tilesX = tilesX; a.rank = c->rank; a.nRanks = c->nRanks;
   a.exitThreshold = c->optExitThreshold; a.leafThreshold = c->optLeafThreshold;

@@ -1,8 +1,8 @@
 """Multi-GPU plumbing (new relative to the reference): one process per GPU,
 torch.distributed over RCCL ("nccl") or gloo.  Nothing here is on the per-ray path.
 
-  tile split   : every rank renders the 8x8-pixel tiles t (raster order) with t % N == rank
-                 (moptix_set_partition); per-pixel seeds depend only on the global pixel index
+  tile split   : every rank renders one 8x8-pixel tile of every group of N tiles (raster order), tile
+                 g * N + (rank + g) % N of group g (moptix_set_partition); per-pixel seeds depend only on the global pixel index
                  and the launch seed, so the gathered frame is bit-identical to a 1-GPU frame.
                  One exchange at the end: gather of the packed tiles to rank 0.
   sample split : every rank renders the whole frame for launches i with i % N == rank; one
@@ -18,7 +18,9 @@ SAMPLE_SPLIT_TOL = 2e-6
 def tile_pixel_indices(width, height, rank, nranks):
     """Global pixel ids (y*W+x, row 0 = bottom) owned by `rank`, in work-item order."""
     tiles_x, tiles_y = (width + 7) // 8, (height + 7) // 8
-    t = np.arange(rank, tiles_x * tiles_y, nranks, dtype=np.int64)
+    g = np.arange((tiles_x * tiles_y + nranks - 1) // nranks, dtype=np.int64)     # groups of nranks tiles in raster order
+    t = g * nranks + (rank + g) % nranks                    # the deal rotates from group to group (megakernel.h item_to_pixel)
+    t = t[t < tiles_x * tiles_y]
     tx, ty = t % tiles_x, t // tiles_x
     inn = np.arange(64, dtype=np.int64)
     x = (tx[:, None] * 8 + (inn & 7)[None, :]).reshape(-1)

@@ -39,7 +39,9 @@ def _worker(rank, world, port, w, h, spp, q):
     acc = np.zeros((h, w, 3), np.float32)
     tiles_x = (w + 7) // 8
     ntiles = tiles_x * ((h + 7) // 8)
-    for t in range(rank, ntiles, world):                      # this rank's tiles only
+    for t in (g * world + (rank + g) % world for g in range((ntiles + world - 1) // world)):      # this rank's tiles only
+        if t >= ntiles:
+            continue
         x0, y0 = (t % tiles_x) * 8, (t // tiles_x) * 8
         sc.render(seeds, accum=acc, region=(x0, y0, min(x0 + 8, w), min(y0 + 8, h)), threads=1)
     frame = D.gather_tiles(torch.from_numpy(acc), w, h, rank, world, dst=0)

@@ -15,7 +15,7 @@ for o in os.environ.get("OPTS", "").split(","):
 NS = [int(x) for x in os.environ.get("NS", "2,4,8").split(",")]
 def timed():
     best = 1e9
-    for rep in range(3):
+    for rep in range(int(os.environ.get('REPS', '4'))):
         ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); ms, n = ctx.kernel_time(); best = min(best, ms + ctx.reduce_time())
     return best
 ctx.load(hs); t1 = timed()
@@ -24,4 +24,4 @@ for n in NS:
     ts = []
     for r in range(n):
         ctx.set_partition(r, n); ctx.load(hs); ts.append(timed())
-    print("N=%d: max %.1f ms min %.1f ms -> efficiency %.1f %% (compute only)" % (n, max(ts), min(ts), 100 * t1 / (n * max(ts))), flush=True)
+    print("N=%d: max %.1f ms min %.1f ms -> efficiency %.1f %% (compute only)  per rank: %s" % (n, max(ts), min(ts), 100 * t1 / (n * max(ts)), " ".join("%.1f" % t for t in ts)), flush=True)
