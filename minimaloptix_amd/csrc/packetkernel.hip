@@ -12,6 +12,11 @@
 // hit.  Same random draws, same decisions, same floating-point operations on the path's values as variants 0-3 (the
 // images are bit-identical); a path of depth k is a chain of k visits instead of up to 4k.
 //
+// Deep paths (LaunchArgs::auxDepth) go one step further: the shadow rays of a hit are traced in slots BORROWED from
+// finished paths, at the same time as the continuation, and joined through three bits of the path slot's LDS flag word
+// (see PoolLds::freeMask, SlotSink, store_flags / arrive_parks / aux_done).  A launch's tail is a handful of paths
+// walking the 256-bounce cap; this makes each of their bounces one dependent ray instead of up to four.
+//
 // Limits (moptix_api.hip falls back to variant 3 otherwise): at most kPacketShadows lights, no Disney material on an
 // analytic primitive (shadow rays then need the brute-force lists at every ray start).
 #include <hip/hip_runtime.h>
@@ -51,8 +56,8 @@ enum { Q_SHADE = 0, Q_GEN = 1, kNumQ = 2, Q_NODE = 2, Q_LEAF = 3, DEST_DONE = 4,
 // one ray row; the leaf pass reads / writes hit (continuation) or att (shadow ray, tinted only).
 struct alignas(16) i4 { int x, y, z, w; };
 struct alignas(128) SlotCold {
-  i4 ctl;       // item, depth, seed, mode | nShadow << 3 | hasBounce << 5 | hasScale << 6
-  v4 thr;       // throughput (of the hit the packet left from: the shadow results are folded with it)
+  i4 ctl;       // item, depth, seed, mode | nShadow << 3 | hasBounce << 5 | hasScale << 6 | holds borrowed slots << 7
+  v4 thr;       // throughput (of the hit the packet left from: the shadow results are folded with it); .w = the three borrowed slots (int bits)
   v4 rad;       // radiance so far
   v4 hit;       // continuation ray: bestTri, bestPrim (int bits), beta, gamma
   v4 bsc;       // weight of the continuation still to be applied at the next visit: brdf, 1/pdf
