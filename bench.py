@@ -249,7 +249,7 @@ def main():
         fabric_gb = traffic.get("traffic_GB_per_launch") if traffic else None
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": fabric_gb,
-                "kernel": "pt_queuekernel (trace)", "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
+                "kernel": "pt_packetkernel (trace)" if ctx.get_option("kernel_variant_used") == 4 else "pt_queuekernel (trace)", "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
                 "algorithmic_bytes_per_launch": int(my_bytes // passes_per_step),
                 "bytes_per_ray": round(my_bytes / max(1, my_rays), 1), "reduce_ms_total": round(reduce_ms, 3),
                 # `achieved` counts ALGORITHMIC bytes and most of them never leave L2 / Infinity Cache: it is the
