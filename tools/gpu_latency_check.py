@@ -4,6 +4,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 from common import M   # noqa: E402
 ctx = M.Context(0)
+for o in os.environ.get("OPTS", "").split(","):      # e.g. OPTS=kernel_variant=4,aux_depth=1
+    if "=" in o:
+        k, v = o.split("="); ctx.set_option(k, int(v))
 rng = random.Random(3)
 worst = (0, None)
 n = int(os.environ.get("N", "300"))
