@@ -71,6 +71,7 @@ struct moptix_context_t {
   DevBuf<uint8_t> dPoolCold; DevBuf<float> dSampleBuf;
 
   int rank = 0, nRanks = 1;
+  double glassFaceShare = 0.0;       // triangles whose material is glass (no next-event estimation at their hits), set by build_accel
   int optExitThreshold = 16, optLeafSize = 4, optBlocksPerCU = 3, optVariant = 3;
   int optTileMajor = 1;
   long long tileHistoryTiles = -1;
@@ -221,7 +222,9 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   // an 8-way share, 125.0 against 127.6 ms for a 4-way share; 492.8 against 492 ms for the whole frame)
   const bool packetOk = hasTris && a.scene.nLights <= 3 && !a.scene.anyDisneyAnalytic;
   const double nSamples = (double)a.nItems * (double)nSeeds;
-  const bool shortLaunch = nSamples < 2.0e8 && nSamples >= 1.0e6 && nSeeds >= 16;
+  // ... and only where hits have shadow rays to pack: a scene that is mostly glass (the 1.1 M-triangle glass knot of
+  // BASELINE config 5: 68.4 ms on variant 3, 75.4 on variant 4) gets nothing from the packet and pays for its wider records
+  const bool shortLaunch = nSamples < 2.0e8 && nSamples >= 1.0e6 && nSeeds >= 16 && c->glassFaceShare <= 0.5;
   const bool usePacket = packetOk && (c->optVariant == 4 || (!c->variantExplicit && c->optAutoPacket != 0 && shortLaunch));
   const bool useQueue = !usePacket && (c->optVariant >= 2) && (hasTris || c->optAnalyticQueue != 0);
   c->lastVariant = usePacket ? 4 : useQueue ? (c->optVariant == 2 ? 2 : 3) : usePool ? 1 : 0;
@@ -551,6 +554,9 @@ int moptix_build_accel(moptix_context c, const char* kind) {
     HIPCHK(c, c->dFaceNrm.upload(c->faceNrm, c->stream), "upload face normals");
     HIPCHK(c, c->dFaceHasNrm.upload(c->faceHasNrm, c->stream), "upload face flags");
     HIPCHK(c, c->dFaceMat.upload(c->faceMat, c->stream), "upload face materials");
+    size_t glassFaces = 0;
+    for (int m : c->faceMat) glassFaces += (c->mats[m].kind == MAT_GLASS || (c->mats[m].kind == MAT_DISNEY && c->mats[m].brdfType == BRDF_GLASS)) ? 1 : 0;
+    c->glassFaceShare = (double)glassFaces / (double)nFaces;
     HIPCHK(c, lbvh_build(c->stream, c->dFacePos.p, c->dFaceNrm.p, c->dFaceHasNrm.p, c->dFaceMat.p, nFaces, c->optLeafSize, c->optBuilder, &c->bvh), "LBVH build");
   }
   HIPCHK(c, hipStreamSynchronize(c->stream), "sync after upload");
