@@ -190,7 +190,8 @@ int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
  *                      under 1e8 samples, else all); the others are what deep paths borrow, see "aux_depth"
  *   "aux_depth"        variant 4: a path this deep (default 16; 0 = never) traces the shadow rays of each hit in slots
  *                      borrowed from finished paths, at the same time as the continuation ray (DESIGN.md "Borrowed slots")
- *   "analytic_queue"   scheduling experiment, see DESIGN.md
+ *   "analytic_queue"   scenes without triangles: 1 = through the queue kernel, 0 = per-lane kernel, -1 (default) = queue
+ *                      kernel from 64 primitives on
  *   "leaf_size"        1..8 triangles per BVH leaf (default 4; takes effect at the next build_accel)
  *   "tile_major"       hand-out order of the (pixel, sample) work items: 0 = sample-major, 1 = all samples of an
  *                      8x8 tile back to back, tiles with the deepest paths of earlier launches first (default),

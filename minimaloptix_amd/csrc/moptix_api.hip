@@ -83,7 +83,7 @@ struct moptix_context_t {
   int optWatchdogMs = 600000;
   int optFastShading = 0;
   int optBuilder = 1;
-  int optAnalyticQueue = 0;
+  int optAnalyticQueue = -1;          // -1 = by primitive count
   int optAutoPacket = 1;
   int lastVariant = -1;              // what the last render ran (get_option "kernel_variant_used")
   bool variantExplicit = false;      // kernel_variant was set by the caller: no automatic choice
@@ -212,9 +212,11 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
 
   const bool hasTris = a.scene.rootRef != kEmptyRef;
   const bool usePool = c->optVariant == 1 && hasTris;
-  // scenes without triangles ("NoAccel") run on the per-lane kernel.  Option "analytic_queue" = 1 sends them through the
-  // queue kernel instead (every ray is finished by the brute-force lists at set-up, inside a full shading batch, and the
-  // slots cycle through the batches); measured: random_spheres 500 92.3 -> 88.3 ms, cornell_quads 16.5 -> 22.9 ms, so off
+  // Scenes without triangles ("NoAccel"): the per-lane kernel, or ("analytic_queue" = 1) the queue kernel, where every ray
+  // is finished by the brute-force lists at set-up, inside a full 64-lane batch, and the slots cycle through the batches.
+  // With the lists read by scalar loads, four spheres per trip (pt_path.h trav_begin): random_spheres (497 + 33 primitives)
+  // 60.6 ms per-lane, 47.8 ms queue (round 1: 92.3); cornell_quads (16 quads) 15.0 / 17.3 ms.  -1 = queue from 64 primitives on.
+  const bool analyticQueue = c->optAnalyticQueue >= 0 ? c->optAnalyticQueue != 0 : (c->spheres.size() + c->quads.size() >= 64);
   // variant 4 (packetkernel.hip, one shading visit per bounce): triangle scenes with at most three lights and no Disney
   // material on an analytic primitive; anything else runs on variant 3
   // ("auto_packet", default on: variant 3 hands a SHORT launch -- fewer than 2e8 samples, e.g. one rank's share of a 4- or
@@ -226,7 +228,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   // BASELINE config 5: 68.4 ms on variant 3, 75.4 on variant 4) gets nothing from the packet and pays for its wider records
   const bool shortLaunch = nSamples < 2.0e8 && nSamples >= 1.0e6 && nSeeds >= 16 && c->glassFaceShare <= 0.5;
   const bool usePacket = packetOk && (c->optVariant == 4 || (!c->variantExplicit && c->optAutoPacket != 0 && shortLaunch));
-  const bool useQueue = !usePacket && (c->optVariant >= 2) && (hasTris || c->optAnalyticQueue != 0);
+  const bool useQueue = !usePacket && (c->optVariant >= 2) && (hasTris || analyticQueue);
   c->lastVariant = usePacket ? 4 : useQueue ? (c->optVariant == 2 ? 2 : 3) : usePool ? 1 : 0;
   a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;
   // Slots without a path are what deep paths borrow for their shadow rays (packetkernel.hip, "aux_depth"); once the work
@@ -628,7 +630,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
   else if (!strcmp(name, "tile_major")) { if (value < 0 || value > 3) return fail(c, MOPTIX_ERR_INVALID, "tile_major in {0,1,2,3}"); c->optTileMajor = value; }
   else if (!strcmp(name, "auto_packet")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "auto_packet in {0,1}"); c->optAutoPacket = value; }
-  else if (!strcmp(name, "analytic_queue")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "analytic_queue in {0,1}"); c->optAnalyticQueue = value; }
+  else if (!strcmp(name, "analytic_queue")) { if (value < -1 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "analytic_queue in {-1,0,1}"); c->optAnalyticQueue = value; }
   else if (!strcmp(name, "aux_depth")) { if (value < 0 || value > 100000) return fail(c, MOPTIX_ERR_INVALID, "aux_depth in [0,100000]"); c->optAuxDepth = value; }
   else if (!strcmp(name, "slots_in_use")) { if (value < -1 || value > 512) return fail(c, MOPTIX_ERR_INVALID, "slots_in_use in [-1,512]"); c->optSlotsInUse = value; }
   else if (!strcmp(name, "builder")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "builder in {0,1}"); if (value != c->optBuilder) c->accelBuilt = false; c->optBuilder = value; }

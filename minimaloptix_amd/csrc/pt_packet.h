@@ -62,8 +62,9 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
     Cdlin = ps.cdlin;
     disney_color_constants(Cdlin, m.specular, m.specularTint, m.sheenTint, m.metallic, Cspec0, Csheen);
   }
-  for (ps.light = 0; ps.light < sc.nLights; ps.light++) {
-    const DevLight* lt = sc.lights + ps.light;
+  for (int li = 0; li < sc.nLights; li++) {                 // li is uniform across the wave: the record is a scalar load
+    const DevLight ltv = load_uniform(sc.lights + li);
+    const DevLight* lt = &ltv;
     cnt<CNT>(ct.lightLoads);
     v3 pointOnLight, normalOnLight;
     if (lt->shape == LIGHT_SPHERE) {

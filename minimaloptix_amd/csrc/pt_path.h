@@ -83,7 +83,36 @@ PT_HD void trav_begin(const SceneView& sc, const PathState& ps, Trav& tv, Counte
   tv.sp = 0; tv.started = 1;
   bool terminated = false;
   if (ps.kind == RK_RADIANCE) {
-    for (int i = 0; i < sc.nSpheres; i++) {               // sphereIntersect, Geometry.cu:18-55
+    int i0 = 0;
+#ifndef PT_SPHERE_CHUNK
+#define PT_SPHERE_CHUNK 4
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Four spheres per trip: their discriminants are four independent chains (one sphere alone is a chain of ~16 dependent
+    // instructions behind a scalar load), the roots are taken only where a discriminant is not negative.  Same operations
+    // per sphere as sphere_roots, and the equal-t rule of potential() makes the outcome independent of the order anyway.
+    for (; i0 + PT_SPHERE_CHUNK <= sc.nSpheres; i0 += PT_SPHERE_CHUNK) {
+      float bq[PT_SPHERE_CHUNK], dq[PT_SPHERE_CHUNK];
+#pragma unroll
+      for (int k = 0; k < PT_SPHERE_CHUNK; k++) {
+        const DevSphere s = load_uniform(sc.spheres + i0 + k);
+        const v3 oc = ps.o - s.center;
+        bq[k] = dot(ps.d, oc);
+        const float c = dot(oc, oc) - s.radius * s.radius;
+        dq[k] = bq[k] * bq[k] - c;
+      }
+#pragma unroll
+      for (int k = 0; k < PT_SPHERE_CHUNK; k++) {
+        if (!(dq[k] < 0)) {
+          const float sq = __builtin_sqrtf(dq[k]);
+          const float t1 = -bq[k] - sq, t2 = -bq[k] + sq;
+          if (potential(t1, i0 + k, ps.tmin, tv.tbest, tv.bestPrim)) { tv.tbest = t1; tv.bestPrim = i0 + k; }
+          else if (potential(t2, i0 + k, ps.tmin, tv.tbest, tv.bestPrim)) { tv.tbest = t2; tv.bestPrim = i0 + k; }
+        }
+      }
+    }
+#endif
+    for (int i = i0; i < sc.nSpheres; i++) {              // sphereIntersect, Geometry.cu:18-55
       const DevSphere s = sc.spheres[i];
       float t1, t2;
       if (sphere_roots(s.center, s.radius, ps.o, ps.d, t1, t2)) {
@@ -92,7 +121,7 @@ PT_HD void trav_begin(const SceneView& sc, const PathState& ps, Trav& tv, Counte
       }
     }
     for (int i = 0; i < sc.nQuads; i++) {                 // quadIntersect, Geometry.cu:70-91
-      const DevQuad q = sc.quads[i];
+      const DevQuad q = load_uniform(sc.quads + i);
       float t; const int id = sc.nSpheres + i;
       if (quad_test(q.plane, q.v1, q.v2, q.anchor, ps.o, ps.d, ps.tmin, ps.tmax, t) &&
           potential(t, id, ps.tmin, tv.tbest, tv.bestPrim)) { tv.tbest = t; tv.bestPrim = id; }
@@ -100,16 +129,16 @@ PT_HD void trav_begin(const SceneView& sc, const PathState& ps, Trav& tv, Counte
     cnt<CNT>(ct.analyticTests, (uint32_t)(sc.nSpheres + sc.nQuads));
   } else if (sc.anyDisneyAnalytic) {
     for (int i = 0; i < sc.nSpheres && !terminated; i++) {
-      const int mat = sc.sphereMat[i];
+      const int mat = load_uniform(sc.sphereMat + i);
       if (sc.mats[mat].kind != MAT_DISNEY) continue;
-      const DevSphere s = sc.spheres[i];
+      const DevSphere s = load_uniform(sc.spheres + i);
       float t1, t2;
       if (sphere_roots(s.center, s.radius, ps.o, ps.d, t1, t2) &&
           ((t1 > ps.tmin && t1 < ps.tmax) || (t2 > ps.tmin && t2 < ps.tmax)))
         terminated = shadow_any_hit(sc, mat, tv.att);
     }
     for (int i = 0; i < sc.nQuads && !terminated; i++) {
-      const DevQuad q = sc.quads[i];
+      const DevQuad q = load_uniform(sc.quads + i);
       if (sc.mats[q.mat].kind != MAT_DISNEY) continue;
       float t;
       if (quad_test(q.plane, q.v1, q.v2, q.anchor, ps.o, ps.d, ps.tmin, ps.tmax, t))

@@ -14,6 +14,26 @@ namespace pt {
 
 // child reference encoding: ref >= 0 -> internal node index; ref < 0 -> leaf, ~ref = (firstTri << 3) | (count-1)
 constexpr int kMaxLeaf = 8;
+// Read-only scene tables that a wave indexes uniformly (spheres, quads, lights).  A persistent kernel that also writes
+// global memory gets a VECTOR load for `table[i]` even when i is uniform (the compiler cannot prove that nothing clobbers
+// the table): 64 lanes fetch the same 16 bytes into 64 x 4 registers.  Reading through the constant address space says
+// the table is not written while the kernel runs, and the load becomes one s_load into scalar registers.
+template <class T>
+PT_HD T load_uniform(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(sizeof(T) % 4 == 0, "whole dwords");
+  typedef __attribute__((address_space(4))) const unsigned int cu32;
+  cu32* w = (cu32*)reinterpret_cast<const unsigned int*>(p);
+  T out;
+  unsigned int* o = reinterpret_cast<unsigned int*>(&out);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) o[i] = w[i];
+  return out;
+#else
+  return *p;
+#endif
+}
+
 PT_HD int make_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
 PT_HD int leaf_first(int ref) { return (~ref) >> 3; }
 PT_HD int leaf_count(int ref) { return ((~ref) & 7) + 1; }

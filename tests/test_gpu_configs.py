@@ -287,18 +287,25 @@ def test_slots_in_use_is_a_scheduling_knob_only(gpu_ctx):
 
 
 def test_analytic_scenes_through_the_queue_kernel(gpu_ctx):
-    """"NoAccel" scenes (spheres / quads only) normally run on the per-lane kernel; option analytic_queue = 1 sends
-    them through the queue kernel, where a ray is finished by the brute-force lists at set-up: same bits."""
+    """"NoAccel" scenes (spheres / quads only) run on the per-lane kernel or, from 64 primitives on (analytic_queue = -1)
+    or when analytic_queue = 1 says so, through the queue kernel, where a ray is finished by the brute-force lists at
+    set-up: same bits."""
     hs = M.HostScene("random_spheres", 160, 90, iarg=97)
     seeds = M.launch_seeds(3)
     gpu_ctx.load(hs)
-    ref, _ = _render(gpu_ctx, seeds)
     try:
+        gpu_ctx.set_option("analytic_queue", 0)
+        ref, _ = _render(gpu_ctx, seeds)
+        assert gpu_ctx.get_option("kernel_variant_used") == 0
         gpu_ctx.set_option("analytic_queue", 1)
         got, _ = _render(gpu_ctx, seeds)
+        assert gpu_ctx.get_option("kernel_variant_used") == 3
+        gpu_ctx.set_option("analytic_queue", -1)
+        auto, _ = _render(gpu_ctx, seeds)
+        assert gpu_ctx.get_option("kernel_variant_used") == 3       # 97 spheres + 33 quads
     finally:
-        gpu_ctx.set_option("analytic_queue", 0)
-    assert np.array_equal(got, ref)
+        gpu_ctx.set_option("analytic_queue", -1)
+    assert np.array_equal(got, ref) and np.array_equal(auto, ref)
     o, _ = oracle_scene(hs).render(seeds)
     assert rmse(got / 3, o / 3) <= RMSE_TIGHT
 
