@@ -218,16 +218,17 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   // 60.6 ms per-lane, 47.8 ms queue (round 1: 92.3); cornell_quads (16 quads) 15.0 / 17.3 ms.  -1 = queue from 64 primitives on.
   const bool analyticQueue = c->optAnalyticQueue >= 0 ? c->optAnalyticQueue != 0 : (c->spheres.size() + c->quads.size() >= 64);
   // variant 4 (packetkernel.hip, one shading visit per bounce): triangle scenes with at most three lights and no Disney
-  // material on an analytic primitive; anything else runs on variant 3
-  // ("auto_packet", default on: variant 3 hands a SHORT launch -- fewer than 2e8 samples, e.g. one rank's share of a 4- or
-  // 8-way split of the benchmark frame -- to variant 4, whose paths have the shorter critical path: 66.7 against 78.4 ms for
-  // an 8-way share, 125.0 against 127.6 ms for a 4-way share; 492.8 against 492 ms for the whole frame)
+  // material on an analytic primitive; anything else runs on variant 3.
+  // "auto_packet" (default on): while "kernel_variant" has not been set, variant 4 is what such a scene runs on from 1e6
+  // samples and 16 launches on.  Its paths have the shorter critical path (one rank's share of an 8-way split of the
+  // benchmark frame: 66.7 against 78.4 ms) and, since the scene tables are read as constants (pt_types.h load_uniform),
+  // its visits are the cheaper ones as well: whole frame 442 against 452 ms, dining room at 64 spp 162 against 193 ms.
   const bool packetOk = hasTris && a.scene.nLights <= 3 && !a.scene.anyDisneyAnalytic;
   const double nSamples = (double)a.nItems * (double)nSeeds;
-  // ... and only where hits have shadow rays to pack: a scene that is mostly glass (the 1.1 M-triangle glass knot of
-  // BASELINE config 5: 68.4 ms on variant 3, 75.4 on variant 4) gets nothing from the packet and pays for its wider records
-  const bool shortLaunch = nSamples < 2.0e8 && nSamples >= 1.0e6 && nSeeds >= 16 && c->glassFaceShare <= 0.5;
-  const bool usePacket = packetOk && (c->optVariant == 4 || (!c->variantExplicit && c->optAutoPacket != 0 && shortLaunch));
+  // ... but only where hits have shadow rays to pack: a scene that is mostly glass (the 1.1 M-triangle glass knot of
+  // BASELINE config 5: 257 ms on variant 3, 283 on variant 4 at 64 spp) gets nothing from the packet and pays for its wider records
+  const bool autoPacket = nSamples >= 1.0e6 && nSeeds >= 16 && c->glassFaceShare <= 0.5;
+  const bool usePacket = packetOk && (c->optVariant == 4 || (!c->variantExplicit && c->optAutoPacket != 0 && autoPacket));
   const bool useQueue = !usePacket && (c->optVariant >= 2) && (hasTris || analyticQueue);
   c->lastVariant = usePacket ? 4 : useQueue ? (c->optVariant == 2 ? 2 : 3) : usePool ? 1 : 0;
   a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;

@@ -54,7 +54,7 @@ struct PacketSink {
 // Material.cu:172-221 for one hit, without the traces (ps.N, ps.V, ps.mat, ps.o set by on_result; ps.light == 0).
 template <bool CNT, bool FAST = false, class Sink = PacketSink>
 PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Counters& ct, const Sink& sink) {
-  const DevMaterial& m = sc.mats[ps.mat];
+  const DevMaterial m = load_uniform(sc.mats + ps.mat);
   packet_clear(pk);
   const Onb onb = make_onb(ps.N);
   v3 Cdlin = m.Cdlin, Cspec0 = m.Cspec0, Csheen = m.Csheen;

@@ -60,7 +60,7 @@ struct PathState {
 
 // disneyAnyHit (Material.cu:225-232). Returns true when the ray is terminated.
 PT_HD bool shadow_any_hit(const SceneView& sc, int mat, v3& att) {
-  const DevMaterial& m = sc.mats[mat];
+  const DevMaterial m = load_uniform(sc.mats + mat);
   if (m.kind != MAT_DISNEY) return false;                 // no any-hit program: does not occlude
   if (m.brdfType == BRDF_GLASS) { att = att * m.color; return false; }
   att = mk3(0.f, 0.f, 0.f);
@@ -200,7 +200,8 @@ PT_HD void planes4(const v4& p, float inv, float noi, float out[4]) {
 template <bool CNT, class Stack>
 PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
   {
-    const Node128* np = sc.nodes + tv.node;
+    const Node128 npv = load_uniform(sc.nodes + tv.node);
+    const Node128* np = &npv;
     const v4 lox = np->lox, loy = np->loy, loz = np->loz, hix = np->hix, hiy = np->hiy, hiz = np->hiz;
     int r[4] = { np->ref[0], np->ref[1], np->ref[2], np->ref[3] };
     cnt<CNT>(ct.nodeFetches);
@@ -239,7 +240,8 @@ PT_HD void leaf_fetch4(const SceneView& sc, int leafRef, int base, LeafChunk& ch
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int k = base + j < count ? base + j : count - 1;
-    const Tri48* tp = sc.tris + (first + k);
+    const Tri48 tpv = load_uniform(sc.tris + (first + k));
+    const Tri48* tp = &tpv;
     ch.p0[j] = tp->p0; ch.e0[j] = tp->e0; ch.e1[j] = tp->e1; ch.mat[j] = tp->mat; ch.prim[j] = tp->prim;
   }
 }
@@ -362,8 +364,10 @@ PT_HD void hit_attributes(const SceneView& sc, const PathState& ps, const Trav& 
     h.front = ray_at(ps.o, ps.d, t); h.back = h.front;
     h.mat = q->mat;
   } else {
-    const Tri48* tp = sc.tris + tv.bestTri;
-    const TriShade* sp = sc.triShade + tv.bestTri;
+    const Tri48 tpv = load_uniform(sc.tris + tv.bestTri);
+    const TriShade spv = load_uniform(sc.triShade + tv.bestTri);
+    const Tri48* tp = &tpv;
+    const TriShade* sp = &spv;
     // both records are requested before either is used: one memory round trip, not two
     const v3 p0 = tp->p0, e0 = tp->e0, e1 = tp->e1;
     const v3 sn0 = sp->n0, sn1 = sp->n1, sn2 = sp->n2;
@@ -410,7 +414,7 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
   cnt<CNT>(ct.closestHits);
   HitAttr h;
   hit_attributes(sc, ps, tv, h);
-  const DevMaterial& m = sc.mats[h.mat];
+  const DevMaterial m = load_uniform(sc.mats + h.mat);
   if (m.kind == MAT_LIGHT) {                                    // light, Material.cu:238-240
     ps.rad = ps.rad + ps.thr * m.emission;
     end_sample(ps);
@@ -462,12 +466,13 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
 // wave.  Same formulas and the same RNG draw order as the reference's program.
 template <bool CNT, bool FAST = false>
 PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
-  const DevMaterial& m = sc.mats[ps.mat];
+  const DevMaterial m = load_uniform(sc.mats + ps.mat);
   int choice = 0;                       // 0 nothing, 1 shadow ray towards a light, 2 BRDF bounce
   v3 L = mk3(0.f, 0.f, 1.f), H = mk3(0.f, 0.f, 1.f), emission = mk3(0.f, 0.f, 0.f);
   float lightDst = 0.f, lightPdf = 0.f;
   while (ps.light < sc.nLights) {
-    const DevLight* lt = sc.lights + ps.light;
+    const DevLight ltv = load_uniform(sc.lights + ps.light);
+    const DevLight* lt = &ltv;
     cnt<CNT>(ct.lightLoads);
     v3 pointOnLight, normalOnLight;
     if (lt->shape == LIGHT_SPHERE) {

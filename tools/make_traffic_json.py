@@ -2,7 +2,7 @@
 
   python3 tools/make_traffic_json.py gpurun_out/prof_bench_<tag> [profiles/traffic.json]
 
-Per-launch counters of the trace kernel (pt_queuekernel<false,true>): FETCH_SIZE and WRITE_SIZE (KB; FETCH_SIZE =
+Per-launch counters of the trace kernel (pt_packetkernel<false,...> or pt_queuekernel<false,...>, whichever ran): FETCH_SIZE and WRITE_SIZE (KB; FETCH_SIZE =
 TCC_EA0_RDREQ x 64 B -- the guide's x2 correction is for wide coalesced streams and is NOT applied to these 16-byte
 gathers), TCC_HIT / TCC_MISS.  The file is stamped with bench.source_hash(): bench.py ignores it for any other
 device code."""
@@ -20,11 +20,13 @@ import bench   # noqa: E402
 src = sys.argv[1]
 dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "profiles", "traffic.json")
 agg, cnt = collections.defaultdict(float), collections.Counter()
+kernels = set()
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r.get("Kernel_Name", "")
-        if "pt_queuekernel<false" not in name:
+        if "pt_queuekernel<false" not in name and "pt_packetkernel<false" not in name:
             continue
+        kernels.add(name.split("(")[0].split("::")[-1])
         k = r.get("Counter_Name")
         agg[k] += float(r.get("Counter_Value", 0)); cnt[k] += 1
 per = {k: agg[k] / cnt[k] for k in agg}
@@ -34,7 +36,7 @@ if any(k not in per for k in need):
 out = {
     "source": "%s (separate --pmc passes of `python3 bench.py --steps 1 --warmup 0`)" % src,
     "source_hash": bench.source_hash(REPO),
-    "kernel": "pt_queuekernel<false,true>",
+    "kernel": ", ".join(sorted(kernels)),
     "FETCH_SIZE_KB_per_launch": per["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": per["WRITE_SIZE"],
     "traffic_GB_per_launch": round((per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024 / 1e9, 1),
     "TCC_HIT_per_launch": per.get("TCC_HIT_sum"), "TCC_MISS_per_launch": per.get("TCC_MISS_sum"),

@@ -22,7 +22,7 @@ for d in sorted(glob.glob("$OUT/*/")):
         agg = collections.defaultdict(float); cnt = collections.Counter()
         for r in csv.DictReader(open(f)):
             k = (r.get("Kernel_Name", "")[:48], r.get("Counter_Name"))
-            if "queuekernel" not in k[0] and "reduce" not in k[0]: continue
+            if "queuekernel" not in k[0] and "packetkernel" not in k[0] and "reduce" not in k[0]: continue
             agg[k] += float(r.get("Counter_Value", 0)); cnt[k] += 1
         for k in sorted(agg): print("   %-48s %-24s sum=%.6g launches=%d per_launch=%.6g" % (k[0], k[1], agg[k], cnt[k], agg[k] / cnt[k]))
 PY

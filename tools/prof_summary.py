@@ -28,9 +28,10 @@ for d in sorted(glob.glob(os.path.join(src, "*/"))):
         agg, cnt = collections.defaultdict(float), collections.Counter()
         for r in csv.DictReader(open(f)):
             name = r.get("Kernel_Name", "")
-            if "queuekernel" not in name and "reduce" not in name:
+            if "queuekernel" not in name and "packetkernel" not in name and "reduce" not in name:
                 continue
-            short = "pt_queuekernel<%s>" % name.split("<")[1].split(">")[0] if "queuekernel" in name else "k_reduce_samples"
+            short = ("pt_%skernel<%s>" % ("packet" if "packetkernel" in name else "queue", name.split("<")[1].split(">")[0])
+                     if "kernel<" in name else "k_reduce_samples")
             k = (short, r.get("Counter_Name"))
             agg[k] += float(r.get("Counter_Value", 0)); cnt[k] += 1
         for k in sorted(agg):
