@@ -181,10 +181,10 @@ int moptix_render_counted(moptix_context ctx, const int32_t* seeds, int32_t nSee
 int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
 
 /* tuning knobs (none of them changes a bit of the image):
- *   "kernel_variant"   0 per-lane kernel (scenes without triangles always use it), 1 per-wave pool, 2 slot queues per wave, 3 slot queues per workgroup (default),
+ *   "kernel_variant"   0 per-lane kernel, 1 per-wave pool, 2 slot queues per wave, 3 slot queues per workgroup,
  *                      4 = 3 with one shading visit per bounce (pt_packet.h; scenes with <= 3 lights, else 3 runs).
- *                      While it has not been set, a short launch (1e6..2e8 samples, >= 16 seeds: one rank's share of a
- *                      multi-GPU frame) runs on 4 ("auto_packet" = 0 turns that off): shorter critical path per path
+ *                      While it has not been set: 4 for launches of >= 1e6 samples and >= 16 seeds on scenes that are not
+ *                      mostly glass ("auto_packet" = 0 turns that off), else 3; scenes without triangles: see "analytic_queue"
  *   "builder"          1 binned-SAH topology over the Morton order (default), 0 Morton radix tree
  *   "slots_in_use"     path slots per 512-slot pool that carry a path (-1 = chosen per launch: 448 for variant 4 launches
  *                      under 1e8 samples, else all); the others are what deep paths borrow, see "aux_depth"
