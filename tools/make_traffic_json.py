@@ -10,6 +10,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import os
 import sys
 
@@ -26,7 +27,7 @@ for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive
         name = r.get("Kernel_Name", "")
         if "pt_queuekernel<false" not in name and "pt_packetkernel<false" not in name:
             continue
-        kernels.add(name.split("(")[0].split("::")[-1])
+        kernels.add(re.search(r"pt_\w+kernel<[^>]*>", name).group(0).replace(" ", ""))
         k = r.get("Counter_Name")
         agg[k] += float(r.get("Counter_Value", 0)); cnt[k] += 1
 per = {k: agg[k] / cnt[k] for k in agg}
