@@ -197,7 +197,7 @@ int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
  *                      8x8 tile back to back, tiles with the deepest paths of earlier launches first (default),
  *                      2 = as 1 with one pixel's samples per wave
  *   "blocks_per_cu"    resident workgroups per CU (default 3)
- *   "swap_lanes", "starve_lanes"   node-loop swap / starvation thresholds of variants 2 and 3
+ *   "swap_lanes", "starve_lanes"   node-loop swap / starvation thresholds of variants 2, 3 and 4
  *   "exit_threshold" (variant 0), "pool_slots" (128|192|256), "refill_lanes", "leaf_threshold" (variant 1)
  *   "sample_buffer_mb" budget of the per-sample buffer (default 16384); larger batches run in passes
  *   "fast_shading"     0 (default): disneyPdf / disneyEval in correctly rounded binary32, bit-parity with the oracle;
