@@ -55,9 +55,9 @@ def _worker(rank, world, port, w, h, spp, q):
     dist.destroy_process_group()
 
 
-def test_tile_split_and_sample_split_world_size_2_gloo():
+@pytest.mark.parametrize("world,w,h,spp", [(2, 72, 40, 4), (3, 70, 37, 3)])       # 3 ranks: ragged tiles, a last group of one tile
+def test_tile_split_and_sample_split_gloo(world, w, h, spp):
     import torch.multiprocessing as mp
-    w, h, spp, world = 72, 40, 4, 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -20,8 +20,14 @@ def timed():
     return best
 ctx.load(hs); t1 = timed()
 print("N=1: %.1f ms" % t1, flush=True)
+SPLIT = os.environ.get("SPLIT", "tile")            # tile: rank r's tiles, all launches; sample: whole frame, launches i = r mod n
+all_seeds = seeds
 for n in NS:
     ts = []
     for r in range(n):
-        ctx.set_partition(r, n); ctx.load(hs); ts.append(timed())
+        if SPLIT == "sample":
+            seeds = all_seeds[r::n]; ctx.set_partition(0, 1)
+        else:
+            ctx.set_partition(r, n)
+        ctx.load(hs); ts.append(timed())
     print("N=%d: max %.1f ms min %.1f ms -> efficiency %.1f %% (compute only)  per rank: %s" % (n, max(ts), min(ts), 100 * t1 / (n * max(ts)), " ".join("%.1f" % t for t in ts)), flush=True)
