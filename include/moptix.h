@@ -194,8 +194,9 @@ int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
  *                      kernel from 64 primitives on
  *   "leaf_size"        1..8 triangles per BVH leaf (default 4; takes effect at the next build_accel)
  *   "tile_major"       hand-out order of the (pixel, sample) work items: 0 = sample-major, 1 = all samples of an
- *                      8x8 tile back to back, tiles with the deepest paths of earlier launches first (default),
- *                      2 = as 1 with one pixel's samples per wave
+ *                      8x8 tile back to back, tiles with the deepest paths of earlier launches first,
+ *                      2 = as 1 with one pixel's samples per wave, 3 = all samples of a pixel back to back, pixels with
+ *                      the deepest paths of earlier launches first (default)
  *   "blocks_per_cu"    resident workgroups per CU (default 3)
  *   "swap_lanes", "starve_lanes"   node-loop swap / starvation thresholds of variants 2, 3 and 4
  *   "exit_threshold" (variant 0), "pool_slots" (128|192|256), "refill_lanes", "leaf_threshold" (variant 1)

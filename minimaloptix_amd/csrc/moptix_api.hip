@@ -73,7 +73,7 @@ struct moptix_context_t {
   int rank = 0, nRanks = 1;
   double glassFaceShare = 0.0;       // triangles whose material is glass (no next-event estimation at their hits), set by build_accel
   int optExitThreshold = 16, optLeafSize = 4, optBlocksPerCU = 3, optVariant = 3;
-  int optTileMajor = 1;
+  int optTileMajor = 3;              // all samples of a pixel back to back, pixels with the deepest paths of earlier launches first
   long long tileHistoryTiles = -1;
   DevBuf<unsigned int> dTileCost, dTileCostSorted; DevBuf<int> dTileOrder, dTileIota; DevBuf<uint8_t> dSortTmp;
   int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 16384, optLeafThreshold = 16, optSwapLanes = 32;

@@ -325,21 +325,21 @@ def test_full_hd_frame_properties(gpu_ctx):
 
 
 def test_work_item_order_does_not_change_the_image(gpu_ctx):
-    """The hand-out order of the (pixel, sample) work items is a scheduling decision: sample-major, tile-major in
-    raster order (first launch) and tile-major with the deepest tiles first (later launches, from the recorded
+    """The hand-out order of the (pixel, sample) work items is a scheduling decision: sample-major, tile- or pixel-major
+    in raster order (first launch) and with the deepest tiles / pixels first (later launches, from the recorded
     history) give the same bits, because every sample lands in its own slot of the per-sample buffer."""
     hs = M.HostScene("file:coffee", 320, 180)
     seeds = M.launch_seeds(6)
     images = []
     try:
-        for tile_major, repeats in ((0, 1), (1, 3)):
+        for tile_major, repeats in ((0, 1), (1, 3), (2, 2), (3, 3)):
             gpu_ctx.set_option("tile_major", tile_major)
             gpu_ctx.load(hs)                                  # a rebuild forgets the history
             for _ in range(repeats):
                 gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
                 images.append(gpu_ctx.accum_read())
     finally:
-        gpu_ctx.set_option("tile_major", 1)
+        gpu_ctx.set_option("tile_major", 3)
     assert all(np.array_equal(images[0], im) for im in images[1:])
     o, _ = oracle_scene(hs).render(seeds)
     assert rmse(images[0] / 6, o / 6) <= RMSE_TIGHT
