@@ -2,7 +2,11 @@
 """bench.py -- BASELINE.json headline benchmark of the MinimalOptiX render path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+runs as typed for every N: with N > 1 and no WORLD_SIZE in the environment it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py ...`
+as a child process BEFORE anything touches the GPU and exits with the child's code (the driver's own torch.distributed.run
+launch sets WORLD_SIZE and goes straight to the worker).
 
 A step = one frame of the metric's configuration: coffee.obj scene (168,193 triangles, LBVH),
 1920x1080, 256 spp = clear + 256 fused launches of the megakernel + ordered sample reduction
@@ -14,6 +18,8 @@ region.  Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,10 +29,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
-# What actually serves the traversal's bytes: the 3.4 MB of nodes and 16 MB of triangle records are L2 / Infinity-Cache
-# resident.  Ceilings for independent random 64-byte gathers measured with tools/micro/gather.hip on MI355X.
-L2_GATHER_GBS = 13200.0     # 3.6 MB table (one XCD's L2 holds it)
-IC_GATHER_GBS = 4300.0      # 38 MB table (Infinity Cache)
+GATHER_CEILING_FILE = os.path.join("profiles", "r03_gather_ceiling.txt")    # output of tools/micro/gather on MI355X
 
 
 def source_hash(repo):
@@ -35,7 +38,10 @@ def source_hash(repo):
     h = hashlib.sha1()
     d = os.path.join(repo, "minimaloptix_amd", "csrc")
     for f in sorted(os.listdir(d)) + ["../../Makefile"]:
-        with open(os.path.join(d, f), "rb") as fh:
+        p = os.path.join(d, f)
+        if not os.path.isfile(p):
+            continue
+        with open(p, "rb") as fh:
             h.update(f.encode()); h.update(fh.read())
     return h.hexdigest()[:16]
 
@@ -45,6 +51,28 @@ def algorithmic_bytes(st, pixels):
     the node record is a four-child 128-byte node (one L2 line) since the binary tree was widened; N_node counts
     those fetches.  N_accum is counted per pixel per launch batch (the per-sample buffer traffic is not claimed)."""
     return 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * pixels
+
+
+def gather_ceilings(repo):
+    """Ceilings of the traversal's access pattern (every lane fetches its own 128-byte record, next address dependent
+    on the data) measured on MI355X with tools/micro/gather.hip; the committed output is the evidence (profiles/).
+    Returns {"l2_128": best TB/s over all occupancies / chains for 128-B records from the 3.1 MB table (one XCD's L2
+    holds it), "l2_128_at_12_waves": the dependent single-chain rate at the trace kernel's own 12 waves per CU,
+    "ic_128": best from the 38 MB table (Infinity Cache)} in GB/s, or None when the file is missing."""
+    try:
+        rows = [l.split() for l in open(os.path.join(repo, GATHER_CEILING_FILE)) if l.strip() and not l.startswith("#")]
+    except OSError:
+        return None
+    best = {}
+    for r in rows:
+        rec, mb, waves, chains, tbs = int(r[0]), float(r[1]), int(r[2]), int(r[3]), float(r[6])
+        if rec != 128:
+            continue
+        for key, ok in (("l2_128", mb < 4.0), ("l2_128_at_12_waves", mb < 4.0 and waves == 12 and chains == 1),
+                        ("ic_128", 30.0 < mb < 50.0)):
+            if ok:
+                best[key] = max(best.get(key, 0.0), tbs * 1000.0)
+    return best if "l2_128" in best else None
 
 
 def cpu_baseline(width, height, target_s):
@@ -83,7 +111,35 @@ def read_traffic(repo):
     return t
 
 
-def main():
+def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per_ray, rays, reduce_ms, kernel, traffic, ceil):
+    """The dominant kernel against the roof that binds it.  The traversal's bytes (SURVEY 8d's algorithmic count) are
+    served by the XCDs' L2s and the Infinity Cache -- the 3.1 MB of nodes and 16 MB of triangle records never leave
+    them -- and every fetch depends on the one before it, so the roof is the chip's rate for dependent per-lane gathers
+    of 128-byte records from an L2-resident table (profiles/r03_gather_ceiling.txt), not HBM.  `frac` is measured
+    against the best rate that micro-benchmark reaches at ANY occupancy; HBM enters as `hbm_frac` (bytes that really
+    crossed the fabric, PMC) and as the SURVEY figure `algorithmic_frac_of_hbm` (can exceed 1: not a physical bound)."""
+    launch_s = launch_ms * 1e-3
+    fabric_gb = traffic.get("traffic_GB_per_launch") if traffic else None
+    peak = ceil["l2_128"] if ceil else None
+    return {
+        "bound": "l2_gather_latency", "achieved": round(achieved_gbs, 1), "peak": round(peak, 1) if peak else None, "unit": "GB/s",
+        "frac": round(achieved_gbs / peak, 4) if peak else None, "traffic": fabric_gb,
+        "peak_source": GATHER_CEILING_FILE + " (tools/micro/gather.hip: dependent per-lane gathers of 128-B records, 3.1 MB table, best over occupancies)",
+        "peak_at_kernel_occupancy_GBps": round(ceil["l2_128_at_12_waves"], 1) if ceil and "l2_128_at_12_waves" in ceil else None,
+        "infinity_cache_gather_GBps": round(ceil["ic_128"], 1) if ceil and "ic_128" in ceil else None,
+        "kernel": kernel, "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
+        "algorithmic_bytes_per_launch": int(bytes_per_launch), "bytes_per_ray": round(bytes_per_ray, 1),
+        "algorithmic_GBps": round(achieved_gbs, 1), "algorithmic_frac_of_hbm": round(achieved_gbs / HBM_PEAK_GBS, 4),
+        "hbm_peak_GBps": HBM_PEAK_GBS,
+        "hbm_frac": round(fabric_gb / launch_s / HBM_PEAK_GBS, 4) if fabric_gb else None,
+        "fabric_GBps": round(fabric_gb / launch_s, 1) if fabric_gb else None,
+        "fabric_bytes_per_ray": round(fabric_gb * 1e9 / max(1, rays), 1) if fabric_gb else None,
+        "tcc_hit_rate": traffic.get("tcc_hit_rate") if traffic else None,
+        "reduce_ms_total": round(reduce_ms, 3),
+    }
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -93,201 +149,268 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--scene", default="file:coffee")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-leg", action="store_true", help="skip the untimed fast_shading comparison leg (PMC passes)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--split", choices=("tile", "sample"), default="tile", help="multi-GPU decomposition (N > 1)")
-    a = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_workers(n, argv, script=None, env=None):
+    """`python bench.py --gpus N` as typed: N fresh worker processes under torch.distributed.run on a port chosen
+    now.  Called before this process has touched the GPU, and it only ever starts CHILD processes (a process that has
+    initialised HIP must not be replaced).  Returns the launcher's exit code; rank 0's JSON line passes through stdout."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script or os.path.abspath(__file__)] + list(argv)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=e)
+
+
+class GpuFrame:
+    """One rank's share of the benchmark frame on its MI355X, through the C ABI (minimaloptix_amd.Context)."""
+    backend = "nccl"
+
+    def __init__(self, a, rank, world, local):
+        import torch
+        import minimaloptix_amd as M
+        from minimaloptix_amd import dist as D
+        self.torch, self.D, self.a = torch, D, a
+        self.rank, self.world = rank, world
+        self.device = torch.device("cuda", local)
+        torch.cuda.set_device(local)
+        self.ctx = M.Context(local)                 # raises when the HIP library / device is missing: no fallback
+        hs = M.HostScene(a.scene, a.width, a.height)
+        # MOPTIX_BENCH_EMULATE_RANKS=n (single process only): render rank 0's share of an n-way tile split, to study a
+        # rank's launch on a 1-GPU box; the JSON line then describes that share, not the frame
+        self.emu = int(os.environ.get("MOPTIX_BENCH_EMULATE_RANKS", "0")) if world == 1 else 0
+        self.part_rank, self.part_n = (0, self.emu) if self.emu > 1 else (rank, world)
+        self.sample_split = a.split == "sample" and self.part_n > 1
+        if self.sample_split:
+            if a.spp % self.part_n:
+                raise SystemExit("--split sample needs spp divisible by the number of ranks")
+        else:
+            self.ctx.set_partition(self.part_rank, self.part_n)
+        self.ctx.load(hs)
+        W, H = a.width, a.height
+        self.accum = torch.zeros(H * W * 3, dtype=torch.float32, device=self.device)
+        self.ctx.accum_bind(self.accum.data_ptr())
+        self.seeds = M.launch_seeds(a.spp)
+        if self.sample_split:
+            self.seeds = D.sample_split_seeds(self.seeds, self.part_rank, self.part_n)      # launches i = rank mod N
+        # Frame pipelining (N > 1, opt-in MOPTIX_BENCH_PIPELINE=1): a rank's launch is short (frame / N) and its last
+        # milliseconds are a drain in which a few deep paths finish while most of the GPU idles.  Two contexts render
+        # alternate frames on their own streams; every frame is still completed and gathered inside the timed region.
+        # Measured +8 % on an emulated 8-way share of one GPU, never run beside RCCL kernels on a real multi-GPU node.
+        self.pipeline = (self.part_n > 1) and os.environ.get("MOPTIX_BENCH_PIPELINE", "0") == "1"
+        self.ctxs, self.accums = [self.ctx], [self.accum]
+        if self.pipeline:
+            ctx2 = M.Context(local)
+            if not self.sample_split:
+                ctx2.set_partition(self.part_rank, self.part_n)
+            ctx2.load(hs)
+            accum2 = torch.zeros(H * W * 3, dtype=torch.float32, device=self.device)
+            ctx2.accum_bind(accum2.data_ptr())
+            self.ctxs.append(ctx2); self.accums.append(accum2)
+        self.pending = [False] * len(self.ctxs)
+        self.frame_no = 0
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def count(self):
+        """Counting launch (untimed): rays and algorithmic bytes of this rank's share of one frame (deterministic)."""
+        a = self.a
+        self.accum.zero_(); self.sync()
+        st = self.ctx.render_counted(self.seeds)
+        px = a.width * a.height if self.sample_split else len(self.D.tile_pixel_indices(a.width, a.height, self.part_rank, self.part_n))
+        return st.rays, algorithmic_bytes(st, px)
+
+    def collect(self, j):                                               # the frame's one collective
+        a = self.a
+        if self.world == 1:
+            return None
+        if self.sample_split:
+            return self.D.reduce_frame(self.accums[j], dst=0)
+        return self.D.gather_tiles(self.accums[j].view(a.height * a.width, 3), a.width, a.height, self.rank, self.world, dst=0)
+
+    def _finish(self, j):                                               # frame in context j: wait for it, collect it
+        if self.pending[j]:
+            self.ctxs[j].sync()
+            self.collect(j)
+            self.pending[j] = False
+
+    def step(self):
+        if not self.pipeline:
+            self.accum.zero_()
+            self.sync()
+            self.ctx.render(self.seeds)                                 # blocking: launches + ordered reduction
+            return self.collect(0)
+        j = self.frame_no % 2
+        self.frame_no += 1
+        self._finish(j)                                                 # the frame launched two steps ago
+        self.accums[j].zero_()
+        self.torch.cuda.current_stream().synchronize()
+        self.ctxs[j].render_async(self.seeds)
+        self.pending[j] = True
+        return None
+
+    def flush(self):                                                    # oldest frame first: same collective order on every rank
+        if self.pipeline:
+            j = self.frame_no % 2
+            self._finish(j); self._finish(1 - j)
+
+    def reset_kernel_time(self):
+        for c in self.ctxs:
+            c.kernel_time(reset=True)
+
+    def kernel_times(self):
+        kms, n, red = 0.0, 0, 0.0
+        for c in self.ctxs:                                             # both contexts when two frames are in flight
+            k_, n_ = c.kernel_time()
+            kms += k_; n += n_; red += c.reduce_time()
+        return kms, n, red
+
+    def fast_leg(self, total_rays):
+        """The reference compiles its programs with -use_fast_math (utils_host.cpp:30-32).  `value` is the exact mode (bit
+        parity with the oracle); the opt-in approximate BRDF arithmetic ("fast_shading": same rays, weights within ~1e-6)
+        is timed beside it on one GPU, outside the timed region, and reported as a separate field."""
+        if self.world != 1 or self.emu > 1 or self.pipeline:
+            return None
+        ctx, accum = self.ctx, self.accum
+        try:
+            ctx.set_option("fast_shading", 1)
+            accum.zero_(); self.sync(); ctx.render(self.seeds)
+            accum.zero_(); self.sync()
+            t0 = time.perf_counter(); ctx.render(self.seeds); self.sync(); tf = time.perf_counter() - t0
+            return {"value": round(total_rays / tf / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(tf * 1e3, 3), "steps": 1,
+                    "note": "option fast_shading = 1 (v_rcp / v_sqrt inside disneyPdf / disneyEval only); not the mode `value` is measured in"}
+        except Exception as e:                                          # never lose the primary metric to the side leg
+            return {"error": str(e)}
+        finally:
+            try:
+                ctx.set_option("fast_shading", 0)
+            except Exception:
+                pass
+
+    def describe(self):
+        info = self.ctx.accel_info()
+        v = self.ctx.get_option("kernel_variant_used")
+        return {"kernel_variant": v, "bvh_nodes": int(info.nNodes), "bvh_depth": int(info.treeDepth),
+                "bvh_build_ms": round(float(info.buildMs), 3),
+                "kernel": "pt_packetkernel (trace)" if v == 4 else "pt_queuekernel (trace)"}
+
+    def parallelism(self):
+        a, world = self.a, self.world
+        if world == 1:
+            par = "single GPU" if self.emu <= 1 else "EMULATION: rank 0 of a %d-way %s split on one GPU" % (self.emu, a.split)
+        elif self.sample_split:
+            par = "sample-split x%d (rank r renders launches i = r mod %d) + RCCL reduce" % (world, world)
+        else:
+            par = "tile-split x%d (8x8 tiles dealt round-robin, rotating per group) + RCCL gather" % world
+        return par + (", two frames in flight" if self.pipeline else "")
+
+    def traffic(self):
+        a = self.a
+        if self.world == 1 and self.emu <= 1 and a.scene == "file:coffee" and (a.width, a.height, a.spp) == (1920, 1080, 256):
+            return read_traffic(REPO)
+        return None
+
+
+def run_rank(a, frame_cls=GpuFrame):
+    """One rank of the benchmark: W untimed warm-up frames, then exactly K frames between barrier + synchronize on both
+    sides, MAX over ranks; rank 0 prints the JSON line.  `frame_cls` is the renderer (GpuFrame; the CPU test of the
+    N > 1 plumbing passes a stand-in that lives under tests/)."""
     import torch
-    import minimaloptix_amd as M
-    from minimaloptix_amd import dist as D
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
-    import torch.distributed as dist
-    # MOPTIX_BENCH_FORCE_DIST=1 brings the RCCL group up for a single rank too (exercises init/barrier/all_reduce
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    # MOPTIX_BENCH_FORCE_DIST=1 brings the process group up for a single rank too (exercises init/barrier/all_reduce
     # on a 1-GPU box); the measured path is unchanged
     use_dist = world > 1 or os.environ.get("MOPTIX_BENCH_FORCE_DIST") == "1"
+    backend = frame_cls.backend
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise SystemExit("MASTER_PORT is not set (start N > 1 ranks through `python bench.py --gpus N` or torch.distributed.run)")
+            os.environ["MASTER_PORT"] = str(free_port())
+        if backend == "nccl":
+            if torch.cuda.device_count() <= local:
+                raise SystemExit("%d devices needed, %d present" % (world, torch.cuda.device_count()))
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    dev = torch.device("cuda", local)
-    if use_dist and world == 1:                 # forced single-rank group: the collectives of the N>1 path, once
+    fr = frame_cls(a, rank, world, local)
+    dev = fr.device
+    if use_dist and world == 1:                     # forced single-rank group: the collectives of the N > 1 path, once
         t = torch.arange(12, dtype=torch.float32, device=dev).reshape(4, 3)
         got = [torch.empty_like(t)]
         dist.gather(t, got, dst=0)
         assert torch.equal(got[0], t)
-    ctx = M.Context(local)                      # raises when the HIP library / device is missing: no fallback
-    hs = M.HostScene(a.scene, a.width, a.height)
-    # MOPTIX_BENCH_EMULATE_RANKS=n (single process only): render rank 0's share of an n-way tile split, to study a
-    # rank's launch on a 1-GPU box; the JSON line then describes that share, not the frame
-    emu = int(os.environ.get("MOPTIX_BENCH_EMULATE_RANKS", "0")) if world == 1 else 0
-    part_rank, part_n = (0, emu) if emu > 1 else (rank, world)
-    sample_split = a.split == "sample" and part_n > 1
-    if sample_split:
-        if a.spp % part_n:
-            raise SystemExit("--split sample needs spp divisible by the number of ranks")
-    else:
-        ctx.set_partition(part_rank, part_n)
-    ctx.load(hs)
-    info = ctx.accel_info()
-    W, H = a.width, a.height
-    accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
-    ctx.accum_bind(accum.data_ptr())
-    seeds = M.launch_seeds(a.spp)
-    if sample_split:
-        seeds = D.sample_split_seeds(seeds, part_rank, part_n)      # launches i = rank mod N (SURVEY 8d seed schedule)
-    # Frame pipelining (N > 1): a rank's launch is short (frame / N), and the last ~20 ms of every launch are a drain in
-    # which a few deep paths finish while most of the GPU idles.  Two contexts render alternate frames on their own
-    # streams, so the next frame fills the CUs the draining one has released; every frame is still completed and
-    # gathered inside the timed region.
-    # Opt-in (MOPTIX_BENCH_PIPELINE=1): measured +8 % on an emulated 8-way share of one GPU, but never run together with
-    # RCCL on a real multi-GPU node, where the gather kernels would have to find room next to a persistent grid.
-    pipeline = (part_n > 1) and os.environ.get("MOPTIX_BENCH_PIPELINE", "0") == "1"
-    ctxs, accums = [ctx], [accum]
-    if pipeline:
-        ctx2 = M.Context(local)
-        if not sample_split:
-            ctx2.set_partition(part_rank, part_n)
-        ctx2.load(hs)
-        accum2 = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
-        ctx2.accum_bind(accum2.data_ptr())
-        ctxs.append(ctx2); accums.append(accum2)
 
     def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        fr.sync()
 
-    # counting launch (untimed): rays and algorithmic bytes of one frame are deterministic
-    accum.zero_(); torch.cuda.synchronize()
-    st = ctx.render_counted(seeds)
-    my_pixels = W * H if sample_split else len(D.tile_pixel_indices(W, H, part_rank, part_n))
-    my_rays, my_bytes = st.rays, algorithmic_bytes(st, my_pixels)
+    my_rays, my_bytes = fr.count()
     tot = torch.tensor([float(my_rays), float(my_bytes)], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tot)
     total_rays, total_bytes = float(tot[0].item()), float(tot[1].item())
 
-    def gather(j):                                                  # the frame's one collective
-        if world == 1:
-            return None
-        if sample_split:
-            return D.reduce_frame(accums[j], dst=0)
-        return D.gather_tiles(accums[j].view(H * W, 3), W, H, rank, world, dst=0)
-
-    pending = [False] * len(ctxs)
-    frame_no = [0]
-
-    def finish(j):                                                  # frame in context j: wait for it, collect it
-        if pending[j]:
-            ctxs[j].sync()
-            gather(j)
-            pending[j] = False
-
-    def step():
-        if not pipeline:
-            accum.zero_()
-            torch.cuda.synchronize()
-            ctx.render(seeds)                                       # blocking: launches + ordered reduction
-            return gather(0)
-        j = frame_no[0] % 2
-        frame_no[0] += 1
-        finish(j)                                                   # the frame launched two steps ago
-        accums[j].zero_()
-        torch.cuda.current_stream().synchronize()
-        ctxs[j].render_async(seeds)
-        pending[j] = True
-        return None
-
-    def flush():                                                    # oldest frame first: same collective order on every rank
-        if pipeline:
-            j = frame_no[0] % 2
-            finish(j); finish(1 - j)
-
     for _ in range(a.warmup):
-        step()
-    flush()
-    for c_ in ctxs:
-        c_.kernel_time(reset=True)
+        fr.step()
+    fr.flush()
+    fr.reset_kernel_time()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
-    flush()
+        fr.step()
+    fr.flush()
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    kms, nlaunch, reduce_ms = 0.0, 0, 0.0
-    for c_ in ctxs:                                                 # both contexts when two frames are in flight
-        k_, n_ = c_.kernel_time()
-        kms += k_; nlaunch += n_; reduce_ms += c_.reduce_time()
-
-    # The reference compiles its programs with -use_fast_math (utils_host.cpp:30-32).  `value` above is the exact mode (bit
-    # parity with the oracle); the opt-in approximate BRDF arithmetic ("fast_shading": same rays, weights within ~1e-6) is
-    # timed beside it on one GPU, outside the timed region, and reported as a separate field.
-    fast = None
-    if world == 1 and emu <= 1 and not pipeline:
-        try:
-            ctx.set_option("fast_shading", 1)
-            accum.zero_(); torch.cuda.synchronize(); ctx.render(seeds)
-            accum.zero_(); torch.cuda.synchronize()
-            tf0 = time.perf_counter(); ctx.render(seeds); torch.cuda.synchronize(); tf = time.perf_counter() - tf0
-            fast = {"value": round(total_rays / tf / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(tf * 1e3, 3), "steps": 1,
-                    "note": "option fast_shading = 1 (v_rcp / v_sqrt inside disneyPdf / disneyEval only); not the mode `value` is measured in"}
-        finally:
-            ctx.set_option("fast_shading", 0)
+    kms, nlaunch, reduce_ms = fr.kernel_times()
+    fast = None if a.no_fast_leg else fr.fast_leg(total_rays)
 
     if rank == 0:
+        W, H = a.width, a.height
         ms_per_step = dt / a.steps * 1e3
         launch_ms = kms / max(1, nlaunch)
         passes_per_step = max(1, nlaunch // max(1, a.steps))
-        achieved = my_bytes / passes_per_step / (launch_ms * 1e-3) / 1e9          # GB/s, rank 0's trace kernel
-        if world == 1:
-            par = "single GPU" if emu <= 1 else "EMULATION: rank 0 of a %d-way %s split on one GPU" % (emu, a.split)
-        elif sample_split:
-            par = "sample-split x%d (rank r renders launches i = r mod %d) + RCCL reduce" % (world, world)
-        else:
-            par = "tile-split x%d (8x8 tiles dealt round-robin, rotating per group) + RCCL gather" % world
-        if pipeline:
-            par += ", two frames in flight"
-        traffic = read_traffic(REPO) if (world == 1 and emu <= 1 and a.scene == "file:coffee" and (W, H, a.spp) == (1920, 1080, 256)) else None
-        fabric_gb = traffic.get("traffic_GB_per_launch") if traffic else None
-        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": fabric_gb,
-                "kernel": "pt_packetkernel (trace)" if ctx.get_option("kernel_variant_used") == 4 else "pt_queuekernel (trace)", "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
-                "algorithmic_bytes_per_launch": int(my_bytes // passes_per_step),
-                "bytes_per_ray": round(my_bytes / max(1, my_rays), 1), "reduce_ms_total": round(reduce_ms, 3),
-                # `achieved` counts ALGORITHMIC bytes and most of them never leave L2 / Infinity Cache: it is the
-                # agreed figure of merit, not HBM bandwidth.  What the memory system really did, from the PMC passes:
-                "served_from": "L2 / Infinity Cache (19 MB working set); see fabric_* for what crossed the fabric",
-                "fabric_GBps": round(fabric_gb / (launch_ms * 1e-3), 1) if fabric_gb else None,
-                "fabric_frac_of_hbm_peak": round(fabric_gb / (launch_ms * 1e-3) / HBM_PEAK_GBS, 4) if fabric_gb else None,
-                "tcc_hit_rate": traffic.get("tcc_hit_rate") if traffic else None,
-                "fabric_bytes_per_ray": round(fabric_gb * 1e9 / max(1, my_rays), 1) if fabric_gb else None,
-                "l2_gather_ceiling_GBps": L2_GATHER_GBS, "frac_of_l2_gather_ceiling": round(achieved / L2_GATHER_GBS, 4),
-                "infinity_cache_gather_ceiling_GBps": IC_GATHER_GBS}
+        achieved = my_bytes / passes_per_step / max(launch_ms * 1e-3, 1e-12) / 1e9        # GB/s, rank 0's trace kernel
+        d = fr.describe()
+        roof = roofline_block(achieved, launch_ms, nlaunch, my_bytes // passes_per_step, my_bytes / max(1, my_rays), my_rays,
+                              reduce_ms, d.pop("kernel"), fr.traffic(), gather_ceilings(REPO))
         out = {
             "metric": "Mrays/s (primary+bounce+shadow rays traced per second, coffee.obj 1920x1080 256spp)",
             "value": round(total_rays / (dt / a.steps) / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "reference scene scenes/coffee (168,193 triangles; Mesh010 missing upstream), synthetic seed schedule tea16(i,0)",
-            "config": {"workload": "coffee.obj LBVH build+traverse, %dx%d, %d spp (BASELINE.json configs[2])" % (W, H, a.spp),
-                       "scene": a.scene, "width": W, "height": H, "spp": a.spp, "rays_per_frame": int(total_rays),
-                       "parallelism": par, "split": a.split if world > 1 else None, "pipeline": bool(pipeline),
-                       "kernel_variant": ctx.get_option("kernel_variant_used"), "bvh_nodes": int(info.nNodes), "bvh_depth": int(info.treeDepth),
-                       "bvh_build_ms": round(float(info.buildMs), 3), "ms_per_frame": round(ms_per_step, 3),
-                       "source_hash": source_hash(REPO)},
+            "data": getattr(fr, "data", "reference scene scenes/coffee (168,193 triangles; Mesh010 missing upstream), synthetic seed schedule tea16(i,0)"),
+            "config": dict({"workload": "coffee.obj LBVH build+traverse, %dx%d, %d spp (BASELINE.json configs[2])" % (W, H, a.spp),
+                            "scene": a.scene, "width": W, "height": H, "spp": a.spp, "rays_per_frame": int(total_rays),
+                            "parallelism": fr.parallelism(), "split": a.split if world > 1 else None,
+                            "pipeline": bool(getattr(fr, "pipeline", False)), "ms_per_frame": round(ms_per_step, 3),
+                            "source_hash": source_hash(REPO)}, **d),
             "roofline": roof,
         }
         if fast is not None:
@@ -298,6 +421,19 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nothing has touched the GPU yet: device_count() reads the driver's list without initialising HIP
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            raise SystemExit("%d devices needed, %d present" % (a.gpus, have))
+        raise SystemExit(launch_workers(a.gpus, argv))
+    run_rank(a)
 
 
 if __name__ == "__main__":

@@ -3,7 +3,11 @@ profiles/traffic.json to the device sources, and the cpu_baseline leg (CPU build
 import json
 import os
 import shutil
+import subprocess
 import sys
+
+import numpy as np
+import pytest
 
 from common import REPO
 
@@ -46,3 +50,56 @@ def test_cpu_baseline_leg_runs_the_cpu_build_of_the_megakernel():
     r = bench.cpu_baseline(96, 54, 0.5)
     assert r["kind"] == "port" and r["unit"] == "Mrays/s" and r["value"] > 0 and r["cores"] >= 1
     assert "LBVH build" in r["sample"] and "excluded" in r["sample"]
+
+
+def test_gather_ceilings_come_from_the_committed_micro_benchmark_output():
+    c = bench.gather_ceilings(REPO)
+    assert c is not None, bench.GATHER_CEILING_FILE
+    # per-lane 16-byte gathers are bounded by one L1 tag lookup per clock per CU: 64 B x 256 CUs x 2.4 GHz = 9.8 TB/s
+    assert 5000 < c["l2_128_at_12_waves"] <= c["l2_128"] < 9900
+    r = bench.roofline_block(8000.0, 440.0, 3, 3.5e12, 1273.0, 2.77e9, 1.0, "k", {"traffic_GB_per_launch": 829.4, "tcc_hit_rate": 0.63}, c)
+    assert r["bound"] == "l2_gather_latency" and 0 < r["frac"] < 1 and r["frac"] == round(8000.0 / r["peak"], 4)
+    assert abs(r["hbm_frac"] - 829.4 / 0.44 / 8000.0) < 1e-3 and r["algorithmic_frac_of_hbm"] == 1.0
+
+
+def test_gpus_2_without_devices_fails_with_a_device_count_not_a_usage_message():
+    # `python bench.py --gpus 2` as typed (no WORLD_SIZE): the launcher path; this container has no GPU
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert p.returncode != 0 and "2 devices needed" in p.stderr, p.stderr[-500:]
+
+
+@pytest.mark.parametrize("split", ["tile", "sample"])
+def test_gpus_2_launcher_path_on_cpu(tmp_path, split):
+    """bench.launch_workers -> torch.distributed.run -> 2 ranks of bench.run_rank over gloo, with the CPU build of the
+    per-lane code standing in for the GPU renderer (tests/bench_stub_worker.py): one JSON line from rank 0, the gathered
+    frame equal to the single-rank frame."""
+    from common import M, hostsim_render
+    w, h, spp = 40, 24, 4
+    frame_file = str(tmp_path / "frame.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["BENCH_STUB_FRAME"] = frame_file
+    env["OMP_NUM_THREADS"] = "2"
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--width", str(w), "--height", str(h), "--spp", str(spp),
+            "--scene", "spheres", "--no-cpu-baseline", "--split", split]
+    out_file = tmp_path / "out.txt"
+    code = ("import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.launch_workers(2, %r, script=%r))"
+            % (REPO, argv, os.path.join(REPO, "tests", "bench_stub_worker.py")))
+    with open(out_file, "w") as fh:
+        rc = subprocess.call([sys.executable, "-c", code], env=env, stdout=fh, stderr=subprocess.STDOUT, timeout=600)
+    text = out_file.read_text()
+    assert rc == 0, text[-2000:]
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, text[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["split"] == split and "STUB" in d["data"]
+    ref, _ = hostsim_render(M.HostScene("spheres", w, h), M.launch_seeds(spp))
+    got = np.load(frame_file)
+    if split == "tile":
+        assert np.array_equal(got, ref)
+    else:
+        assert np.allclose(got, ref, rtol=0, atol=2e-6 * spp)

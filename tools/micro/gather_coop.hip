@@ -1,0 +1,89 @@
+// Micro-benchmark (experiment): three ways for a wave to fetch 64 random 128-byte BVH nodes, one per lane, in a
+// dependent chain (the next node index comes out of the node just read):
+//   A  per lane: 7 x global_load_dwordx4 of the lane's own node (what the trace kernel does)
+//   B  cooperative, LDS-DMA: 8 lanes fetch the 8 quarters of one node with ONE global_load_lds_dwordx4 (4 adjacent lanes =
+//      64 contiguous bytes), 8 instructions cover the wave's 64 nodes; the owner then reads its node from LDS (7 x ds_read_b128)
+//   C  as B through registers: global_load_dwordx4 + ds_write_b128
+// usage: gather_coop [tableMB] [wavesPerCU]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+struct alignas(16) f4 { float x, y, z, w; };
+__device__ __forceinline__ unsigned lcg(unsigned& s) { s = 1664525u * s + 1013904223u; return s; }
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gather(const f4* __restrict__ recs, unsigned nRecs, int iters, float* out) {
+  __shared__ f4 stage[4][64 * 8];          // per wave: 64 nodes x 8 quarters = 8 KB
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned s = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+  float acc = 0.f;
+  unsigned idx = lcg(s) % nRecs;
+  f4* st = stage[wave];
+  for (int it = 0; it < iters; it++) {
+    f4 v[7];
+    if (MODE == 0) {
+      const f4* p = recs + (size_t)idx * 8;
+#pragma unroll
+      for (int q = 0; q < 7; q++) v[q] = p[q];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int owner = 8 * i + (lane >> 3);
+        const unsigned oidx = __shfl(idx, owner);
+        const f4* src = recs + (size_t)oidx * 8 + (lane & 7);
+        if (MODE == 1) {
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                           (void __attribute__((address_space(3)))*)(st + i * 64), 16, 0, 0);
+        } else {
+          st[i * 64 + lane] = *src;
+        }
+      }
+      if (MODE == 1) __builtin_amdgcn_s_waitcnt(0x0f70 & ~0xf);   // vmcnt(0)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+      for (int q = 0; q < 7; q++) v[q] = st[lane * 8 + q];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 7; q++) a += v[q].x + v[q].y;
+    acc += a;
+    idx = (lcg(s) + (unsigned)(__float_as_uint(v[6].w) & 0xff)) % nRecs;
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+int main(int argc, char** argv) {
+  const double mb = argc > 1 ? atof(argv[1]) : 3.1;
+  const int wavesPerCU = argc > 2 ? atoi(argv[2]) : 12;
+  const int only = argc > 3 ? atoi(argv[3]) : -1;
+  hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0);
+  const int cus = prop.multiProcessorCount;
+  const unsigned nRecs = (unsigned)(mb * 1e6 / 128);
+  std::vector<f4> h((size_t)nRecs * 8);
+  for (size_t i = 0; i < h.size(); i++) h[i] = { (float)(i & 7), 1.f, 2.f, (float)((i * 7) & 255) * 1e-30f };
+  f4* d; float* out;
+  const int blocks = cus * wavesPerCU / 4, iters = 2000;
+  (void)hipMalloc(&d, h.size() * sizeof(f4)); (void)hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
+  (void)hipMemcpy(d, h.data(), h.size() * sizeof(f4), hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int mode = 0; mode < 3; mode++) {
+    if (only >= 0 && mode != only) continue;
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+      (void)hipEventRecord(e0);
+      if (mode == 0) k_gather<0><<<blocks, 256>>>(d, nRecs, iters, out);
+      if (mode == 1) k_gather<1><<<blocks, 256>>>(d, nRecs, iters, out);
+      if (mode == 2) k_gather<2><<<blocks, 256>>>(d, nRecs, iters, out);
+      (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+      if (rep > 0 && ms < best) best = ms;
+    }
+    const double recs = (double)blocks * 256 * iters;
+    printf("mode %c table %.1f MB waves/CU %d: %.3f ms  %.1f Gnodes/s  %.2f TB/s (128 B per node)  %.0f ns per dependent step\n", "ABC"[mode], mb, wavesPerCU, best,
+           recs / best / 1e6, recs * 128 / best / 1e9, best * 1e6 / iters);
+  }
+  printf("%s\n", hipGetErrorString(hipGetLastError()));
+  return 0;
+}

@@ -2,17 +2,17 @@
 # rocprofv3 evidence for the bench.py command (run on the GPU box via gpurun):
 #   kernel-trace --stats of `python3 bench.py` and separate PMC passes for HBM traffic.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_bench_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$(pwd)
 run() { name=$1; shift; args=$1; shift; (cd /tmp && timeout -k 5 240 rocprofv3 "$@" --output-format csv -d $ROOT/$OUT/$name -- python3 $ROOT/bench.py $args > $ROOT/$OUT/$name.log 2>&1; echo "pass $name rc=$?"); }
 run kt "--steps 3 --warmup 1 --no-cpu-baseline" --kernel-trace --stats
-run fetch "--steps 1 --warmup 0 --no-cpu-baseline" --kernel-trace --pmc FETCH_SIZE
-run write "--steps 1 --warmup 0 --no-cpu-baseline" --kernel-trace --pmc WRITE_SIZE
-run l2 "--steps 1 --warmup 0 --no-cpu-baseline" --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
-run sq "--steps 1 --warmup 0 --no-cpu-baseline" --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+run fetch "--steps 1 --warmup 0 --no-cpu-baseline --no-fast-leg" --kernel-trace --pmc FETCH_SIZE
+run write "--steps 1 --warmup 0 --no-cpu-baseline --no-fast-leg" --kernel-trace --pmc WRITE_SIZE
+run l2 "--steps 1 --warmup 0 --no-cpu-baseline --no-fast-leg" --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+run sq "--steps 1 --warmup 0 --no-cpu-baseline --no-fast-leg" --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 for f in $OUT/*.log; do echo "== $f"; grep -h '"metric"' $f | cut -c1-400; done
 for f in $(find $OUT/kt -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
 python3 - <<PY

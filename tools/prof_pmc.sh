@@ -23,8 +23,9 @@ for d in sorted(glob.glob("$OUT/pmc*")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(float); cnt = collections.Counter()
         for r in csv.DictReader(open(f)):
-            if "queuekernel" not in r.get("Kernel_Name", ""): continue
-            k = r.get("Counter_Name")
+            n = r.get("Kernel_Name", "")
+            if "queuekernel" not in n and "packetkernel" not in n: continue
+            k = (n[n.find("pt_"):][:40], r.get("Counter_Name"))
             agg[k] += float(r.get("Counter_Value", 0)); cnt[k] += 1
-        for k in sorted(agg): print("   %-28s per_launch=%.6g (n=%d)" % (k, agg[k] / cnt[k], cnt[k]))
+        for k in sorted(agg): print("   %-40s %-28s per_launch=%.6g (n=%d)" % (k[0], k[1], agg[k] / cnt[k], cnt[k]))
 PY
