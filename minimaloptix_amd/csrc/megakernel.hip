@@ -43,10 +43,14 @@ struct LaneStack {
   __device__ __forceinline__ int load(int sp) const {
     return sp < kLdsStack ? lds[sp * 64] : ovf[(size_t)(sp - kLdsStack) * ovfStride];
   }
+  __device__ __forceinline__ bool roomy(int sp) const { return sp + 3 <= kLdsStack; }
+  __device__ __forceinline__ void store_fast(int sp, int v) { lds[sp * 64] = v; }
 };
 struct NoStack {
   __device__ __forceinline__ void store(int, int) {}
   __device__ __forceinline__ int load(int) const { return kTravDone; }
+  __device__ __forceinline__ bool roomy(int) const { return false; }
+  __device__ __forceinline__ void store_fast(int, int) {}
 };
 
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }

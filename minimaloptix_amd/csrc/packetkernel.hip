@@ -37,6 +37,9 @@ constexpr int kWaves = kBlockThreads / 64;
 #ifndef PT_STACKN
 #define PT_STACKN 11
 #endif
+#ifndef PT_QUAD_FETCH
+#define PT_QUAD_FETCH 0      // 1 = node loop: the four lanes of a quad fetch their nodes together (pt_path.h trav_node_step_quad); measured 508 ms against 440 ms per frame
+#endif
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 3
 #endif
@@ -168,6 +171,8 @@ struct SlotStack {
     if (__builtin_expect(sp < kStackN, 1)) v = lds[sp]; else v = ovf[sp - kStackN];
     return v;
   }
+  __device__ __forceinline__ bool roomy(int sp) const { return sp + 3 <= kStackN; }     // three pushes stay in LDS
+  __device__ __forceinline__ void store_fast(int sp, int v) { lds[sp] = v; }
 };
 
 __device__ __forceinline__ float node_inv(float d) {      // slab_inv (pt_path.h) with the hardware reciprocal
@@ -747,7 +752,11 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         const int n = __popcll(m);
         if (n == 0 || nActive - n >= a.swapLanes) break;
         if (CNT) { nodeSteps++; nodeLanes += (uint32_t)n; }
+#if PT_QUAD_FETCH
+        trav_node_step_quad<CNT>(sc, nray, ntv, st, ct, atNode);
+#else
         if (atNode) trav_node_step<CNT>(sc, nray, ntv, st, ct);
+#endif
       }
     }
     PT_STAMP(tNode);

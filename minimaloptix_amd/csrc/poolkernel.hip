@@ -56,6 +56,8 @@ struct LaneStack16 {
   __device__ __forceinline__ int load(int sp) const {
     return sp < kStackN ? lds[sp * 64] : ovf[(size_t)(sp - kStackN) * ovfStride];
   }
+  __device__ __forceinline__ bool roomy(int sp) const { return sp + 3 <= kStackN; }
+  __device__ __forceinline__ void store_fast(int sp, int v) { lds[sp * 64] = v; }
 };
 
 __device__ __forceinline__ int lane_rank(unsigned long long mask) {

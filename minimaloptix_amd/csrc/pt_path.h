@@ -197,52 +197,139 @@ PT_HD void planes4(const v4& p, float inv, float noi, float out[4]) {
   out[0] = fma_(p.x, inv, noi); out[1] = fma_(p.y, inv, noi); out[2] = fma_(p.z, inv, noi); out[3] = fma_(p.w, inv, noi);
 }
 #endif
+#ifndef PT_STACK_ROOMY
+#define PT_STACK_ROOMY 1
+#endif
+// The slab tests, the sort and the pushes of one four-child node whose record is already in registers.
 template <bool CNT, class Stack>
-PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
-  {
-    const Node128 npv = load_uniform(sc.nodes + tv.node);
-    const Node128* np = &npv;
-    const v4 lox = np->lox, loy = np->loy, loz = np->loz, hix = np->hix, hiy = np->hiy, hiz = np->hiz;
-    int r[4] = { np->ref[0], np->ref[1], np->ref[2], np->ref[3] };
-    cnt<CNT>(ct.nodeFetches);
-    const float kFar = 3.0e38f;
-    float ax[4], bx[4], ay[4], by[4], az[4], bz[4], t[4];
-    planes4(lox, tv.inv.x, tv.noi.x, ax); planes4(hix, tv.inv.x, tv.noi.x, bx);
-    planes4(loy, tv.inv.y, tv.noi.y, ay); planes4(hiy, tv.inv.y, tv.noi.y, by);
-    planes4(loz, tv.inv.z, tv.noi.z, az); planes4(hiz, tv.inv.z, tv.noi.z, bz);
+PT_HD void node_step_with(const PathState& ps, Trav& tv, Stack& st, Counters& ct, const v4& lox, const v4& loy, const v4& loz,
+                          const v4& hix, const v4& hiy, const v4& hiz, int r0, int r1, int r2, int r3) {
+  int r[4] = { r0, r1, r2, r3 };
+  cnt<CNT>(ct.nodeFetches);
+  const float kFar = 3.0e38f;
+  float ax[4], bx[4], ay[4], by[4], az[4], bz[4], t[4];
+  planes4(lox, tv.inv.x, tv.noi.x, ax); planes4(hix, tv.inv.x, tv.noi.x, bx);
+  planes4(loy, tv.inv.y, tv.noi.y, ay); planes4(hiy, tv.inv.y, tv.noi.y, by);
+  planes4(loz, tv.inv.z, tv.noi.z, az); planes4(hiz, tv.inv.z, tv.noi.z, bz);
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const float tn = fmaxf_(fmaxf_(fminf_(ax[k], bx[k]), fminf_(ay[k], by[k])), fmaxf_(fminf_(az[k], bz[k]), ps.tmin));
-      const float tf = fminf_(fminf_(fmaxf_(ax[k], bx[k]), fmaxf_(ay[k], by[k])), fminf_(fmaxf_(az[k], bz[k]), tv.tbest));
-      t[k] = (tn <= tf * 1.0000005f && r[k] != kEmptyRef) ? tn : kFar;
-    }
-    sort2(t[0], r[0], t[1], r[1]); sort2(t[2], r[2], t[3], r[3]); sort2(t[0], r[0], t[2], r[2]);
-    sort2(t[1], r[1], t[3], r[3]); sort2(t[1], r[1], t[2], r[2]);
-    if (t[0] < kFar) {
+#endif
+  for (int k = 0; k < 4; k++) {
+    const float tn = fmaxf_(fmaxf_(fminf_(ax[k], bx[k]), fminf_(ay[k], by[k])), fmaxf_(fminf_(az[k], bz[k]), ps.tmin));
+    const float tf = fminf_(fminf_(fmaxf_(ax[k], bx[k]), fmaxf_(ay[k], by[k])), fminf_(fmaxf_(az[k], bz[k]), tv.tbest));
+    t[k] = (tn <= tf * 1.0000005f && r[k] != kEmptyRef) ? tn : kFar;
+  }
+  sort2(t[0], r[0], t[1], r[1]); sort2(t[2], r[2], t[3], r[3]); sort2(t[0], r[0], t[2], r[2]);
+  sort2(t[1], r[1], t[3], r[3]); sort2(t[1], r[1], t[2], r[2]);
+  if (t[0] < kFar) {
+    // one test for the step instead of one per push: do three more entries fit the stack's fast part?
+    if (PT_STACK_ROOMY && st.roomy(tv.sp)) {
+      if (t[3] < kFar) { st.store_fast(tv.sp, r[3]); tv.sp++; }
+      if (t[2] < kFar) { st.store_fast(tv.sp, r[2]); tv.sp++; }
+      if (t[1] < kFar) { st.store_fast(tv.sp, r[1]); tv.sp++; }
+    } else {
       if (t[3] < kFar) { st.store(tv.sp, r[3]); tv.sp++; }
       if (t[2] < kFar) { st.store(tv.sp, r[2]); tv.sp++; }
       if (t[1] < kFar) { st.store(tv.sp, r[1]); tv.sp++; }
-      tv.node = r[0];
-    } else {
-      trav_pop(tv, st);
     }
+    tv.node = r[0];
+  } else {
+    trav_pop(tv, st);
   }
 }
+template <bool CNT, class Stack>
+PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
+  const Node128 npv = load_uniform(sc.nodes + tv.node);
+  node_step_with<CNT>(ps, tv, st, ct, npv.lox, npv.loy, npv.loz, npv.hix, npv.hiy, npv.hiz, npv.ref[0], npv.ref[1], npv.ref[2], npv.ref[3]);
+}
+
+#if defined(__HIPCC__)
+// Quad-cooperative node fetch (kernels whose node loop runs with the whole wave converged).  The L1 of a CU takes ONE per-lane
+// address per clock: a lane fetching its own 128-byte node with 7 x dwordx4 costs 7 look-ups, and with 64 lanes on 64
+// different nodes the address path, not the bytes, is what the node loop waits for (tools/micro/gather_coop.hip,
+// profiles/r03_gather_ceiling.txt).  Four adjacent lanes reading 64 contiguous bytes are one look-up, so the four lanes of a
+// quad fetch the nodes of the quad together: in round r all four read the node of the quad's lane r (lane p the quarters p
+// and p + 4 of its 8 x 16 bytes), and a 4 x 4 transpose inside the quad (two DPP butterfly stages, no LDS) hands every lane
+// the 7 quarters of its own node.  8 loads of 2 look-ups per (quad, round) with an active owner instead of 7 per active
+// lane; the values that reach node_step_with are the same bits.
+template <int BIT> __device__ __forceinline__ float quad_xchg(float send) {       // the value `send` of lane ^ (1 << BIT)
+  constexpr int ctrl = BIT == 0 ? 0xB1 : 0x4E;                                     // quad_perm [1,0,3,2] / [2,3,0,1]
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), ctrl, 0xf, 0xf, true));
+}
+// m[q] := what lane q of the quad held in m[own lane index]; every lane of the wave must be active here (DPP reads lanes)
+__device__ __forceinline__ void quad_transpose(float m[4], bool b0, bool b1) {
+  {
+    const float s01 = b0 ? m[0] : m[1], s23 = b0 ? m[2] : m[3];
+    const float r01 = quad_xchg<0>(s01), r23 = quad_xchg<0>(s23);
+    m[0] = b0 ? r01 : m[0]; m[1] = b0 ? m[1] : r01; m[2] = b0 ? r23 : m[2]; m[3] = b0 ? m[3] : r23;
+  }
+  {
+    const float s02 = b1 ? m[0] : m[2], s13 = b1 ? m[1] : m[3];
+    const float r02 = quad_xchg<1>(s02), r13 = quad_xchg<1>(s13);
+    m[0] = b1 ? r02 : m[0]; m[2] = b1 ? m[2] : r02; m[1] = b1 ? r13 : m[1]; m[3] = b1 ? m[3] : r13;
+  }
+}
+// Wave-collective: `active` lanes stand at the node tv.node; the others only help with the fetch.
+template <bool CNT, class Stack>
+__device__ __forceinline__ void trav_node_step_quad(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct, bool active) {
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int p = lane & 3;
+  const int mine = active ? tv.node : -1;
+  const int o4[4] = { __builtin_amdgcn_mov_dpp(mine, 0x00, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(mine, 0x55, 0xf, 0xf, true),
+                      __builtin_amdgcn_mov_dpp(mine, 0xAA, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(mine, 0xFF, 0xf, 0xf, true) };   // quad_perm [r,r,r,r]
+  v4 a[2][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    a[0][r] = mk4(0.f, 0.f, 0.f, 0.f); a[1][r] = mk4(0.f, 0.f, 0.f, 0.f);
+    if (o4[r] >= 0) {
+      const v4* src = reinterpret_cast<const v4*>(sc.nodes + o4[r]) + p;
+      a[0][r] = load_uniform(src); a[1][r] = load_uniform(src + 4);
+    }
+  }
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+  v4 q[8];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    float mx[4] = { a[h][0].x, a[h][1].x, a[h][2].x, a[h][3].x }, my[4] = { a[h][0].y, a[h][1].y, a[h][2].y, a[h][3].y };
+    float mz[4] = { a[h][0].z, a[h][1].z, a[h][2].z, a[h][3].z }, mw[4] = { a[h][0].w, a[h][1].w, a[h][2].w, a[h][3].w };
+    quad_transpose(mx, b0, b1); quad_transpose(my, b0, b1); quad_transpose(mz, b0, b1); quad_transpose(mw, b0, b1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[4 * h + k] = mk4(mx[k], my[k], mz[k], mw[k]);
+  }
+  // Node128: lox loy loz hix | hiy hiz ref[4] (count, pad)
+  if (active) node_step_with<CNT>(ps, tv, st, ct, q[0], q[1], q[2], q[3], q[4], q[5], f2i(q[6].x), f2i(q[6].y), f2i(q[6].z), f2i(q[6].w));
+}
+#endif
 
 // One leaf (count x 48-byte triangle records) for a lane with tv.node < 0.  The records of up to four
 // triangles are fetched together (one memory round trip per chunk instead of one per triangle; slots past the
 // end of the leaf re-read its last record, which costs no extra line) and then tested in order.  A caller that
 // knows the leaf early (queuekernel.hip: from LDS) issues leaf_fetch4 for the first chunk itself, together with
 // its other loads.
+#ifndef PT_LEAF_PRED
+#define PT_LEAF_PRED 0      // measured: 233 ms against 218 ms at 128 spp -- the four exec-masked regions cost more than the look-ups they save
+#endif
 struct LeafChunk { v3 p0[4], e0[4], e1[4]; int mat[4], prim[4]; };
 PT_HD void leaf_fetch4(const SceneView& sc, int leafRef, int base, LeafChunk& ch) {
   const int first = leaf_first(leafRef), count = leaf_count(leafRef);
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
+#endif
   for (int j = 0; j < 4; j++) {
+#if PT_LEAF_PRED
+    // records past the end of the leaf are not requested at all: every per-lane request is a look-up in the CU's L1,
+    // whose rate (one per clock), not the bytes, is what per-lane gathers are bounded by
+    ch.p0[j] = mk3(0.f, 0.f, 0.f); ch.e0[j] = mk3(0.f, 0.f, 0.f); ch.e1[j] = mk3(0.f, 0.f, 0.f); ch.mat[j] = 0; ch.prim[j] = 0;
+    if (base + j < count) {
+      const Tri48 tpv = load_uniform(sc.tris + (first + base + j));
+      ch.p0[j] = tpv.p0; ch.e0[j] = tpv.e0; ch.e1[j] = tpv.e1; ch.mat[j] = tpv.mat; ch.prim[j] = tpv.prim;
+    }
+#else
     const int k = base + j < count ? base + j : count - 1;
     const Tri48 tpv = load_uniform(sc.tris + (first + k));
     const Tri48* tp = &tpv;
     ch.p0[j] = tp->p0; ch.e0[j] = tp->e0; ch.e1[j] = tp->e1; ch.mat[j] = tp->mat; ch.prim[j] = tp->prim;
+#endif
   }
 }
 template <bool CNT, class Stack>

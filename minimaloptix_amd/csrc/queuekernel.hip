@@ -145,6 +145,8 @@ struct SlotStack {
     if (__builtin_expect(sp < kStackN, 1)) v = lds[sp]; else v = ovf[sp - kStackN];
     return v;
   }
+  __device__ __forceinline__ bool roomy(int sp) const { return sp + 3 <= kStackN; }     // three pushes stay in LDS
+  __device__ __forceinline__ void store_fast(int sp, int v) { lds[sp] = v; }
 };
 
 __device__ __forceinline__ float node_inv(float d) {      // slab_inv (pt_path.h) with the hardware reciprocal

@@ -139,6 +139,12 @@ def lib():
         L.orc_tex2d.argtypes = [C.POINTER(OrcTexture), C.c_float, C.c_float, C.c_float * 4]
         L.orc_tex2d.restype = None
         L.orc_num_threads.restype = C.c_int
+        L.orc_render_clamp_stats.restype = C.c_int
+        L.orc_render_clamp_stats.argtypes = [C.POINTER(OrcScene), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_render_by_depth.restype = C.c_int
+        L.orc_render_by_depth.argtypes = [C.POINTER(OrcScene), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _lib = L
     return _lib
 
@@ -268,6 +274,30 @@ class Scene:
         if rc != 0:
             raise RuntimeError("orc_render failed rc=%d" % rc)
         return accum, st
+
+    def render_by_depth(self, seeds, n_buckets=64, region=None):
+        """Analysis: (colourSum[H,W,K,3], count[H,W,K]) of the clamped samples by the deepest radiance rtTrace of the sample
+        (pt_oracle.c orc_render_by_depth): the image under a stack overflow at depth D is a sum over these buckets."""
+        seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.int32))
+        cs = np.zeros((self.height, self.width, n_buckets, 3), np.float32)
+        cn = np.zeros((self.height, self.width, n_buckets), np.float32)
+        x0, y0, x1, y1 = region if region is not None else (0, 0, self.width, self.height)
+        rc = lib().orc_render_by_depth(C.byref(self.c), _ptr(seeds, C.c_int32), len(seeds), x0, y0, x1, y1, n_buckets,
+                                       _ptr(cs, C.c_float), _ptr(cn, C.c_float))
+        if rc != 0:
+            raise RuntimeError("orc_render_by_depth failed rc=%d" % rc)
+        return cs, cn
+
+    def render_clamp_stats(self, seeds, region, cap=1e3):
+        """Analysis: (rawSum, nClamped, clampedSum), each [H,W,3], of the samples in `region` before / after Camera.cu:39's clamp."""
+        seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.int32))
+        out = [np.zeros((self.height, self.width, 3), np.float32) for _ in range(3)]
+        x0, y0, x1, y1 = region
+        rc = lib().orc_render_clamp_stats(C.byref(self.c), _ptr(seeds, C.c_int32), len(seeds), x0, y0, x1, y1, float(cap),
+                                          *[_ptr(a, C.c_float) for a in out])
+        if rc != 0:
+            raise RuntimeError("orc_render_clamp_stats failed rc=%d" % rc)
+        return out
 
     def closest_hit(self, org, dirn, tmin=1e-3, tmax=1e27):
         t = C.c_float(0)

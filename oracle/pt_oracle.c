@@ -124,6 +124,17 @@ float orc_rand(int32_t* seed) { return (float)orc_lcg(seed) / (float)0x01000000;
 int32_t orc_launch_seed(uint32_t i, uint32_t baseSeed) { return (int32_t)orc_tea16(i, baseSeed); }
 
 /* utils_device.h:36-43 */
+static int g_disney_binary64 = 0;
+/* ANALYSIS switches for the comparison with demo/coffee.png (DESIGN.md "coffee.png pin"); all off = the restated reference.
+ *   indirect_scale_pct : the BRDF-bounce term of the disney program (Material.cu:217-219) is multiplied by pct/100 at every depth
+ *   indirect_depth1_off: ... is dropped at the camera-visible hit only (what is left is emission + next-event estimation there)
+ *   shadow_leak_pct    : a shadow ray that an opaque surface would block gets through with this probability (in 1/100 %) */
+static int g_indirect_scale_pct = 100, g_indirect_depth1_off = 0;
+/*   draw_order         : C++ leaves the evaluation order of `a * rand(s) + b * rand(s)` and of function arguments unspecified
+ *                        (SURVEY A2 assumes left to right).  bit 0: the quad light's two draws swapped (Material.cu:180),
+ *                        bit 1: cosine_sample_hemisphere's two arguments swapped (disney.h:13), bit 2: the camera's jitter pair (Camera.cu:28) */
+static int g_draw_order = 0;
+
 static f3 rand_in_unit_sphere(int32_t* seed) {
   f3 res;
   do {
@@ -287,6 +298,7 @@ static void disney_sample(int32_t* seed, const OrcMaterial* m, f3 N, f3 V, f3* L
   Onb onb = onb_make(N);
   if (orc_rand(seed) < diffuseRatio) {
     float u1 = orc_rand(seed), u2 = orc_rand(seed);
+    if (g_draw_order & 2) { float t_ = u1; u1 = u2; u2 = t_; }
     f3 l = cosine_sample_hemisphere(u1, u2);
     l = onb_inverse(&onb, l);
     *L = norm3(l);
@@ -457,9 +469,11 @@ static d3 disney_eval_d(const OrcMaterial* m, f3 baseColor, d3 N, d3 L, d3 V, d3
   double cc = 0.25 * (double)m->clearcoat * Gr * Fr * Dr;
   return dmk(diffuse.x + spec.x + cc, diffuse.y + spec.y + cc, diffuse.z + spec.z + cc);
 }
-static int g_disney_binary64 = 0;
 int orc_set_option(const char* name, int value) {
   if (!strcmp(name, "disney_binary64")) { g_disney_binary64 = value != 0; return 0; }
+  if (!strcmp(name, "indirect_scale_pct")) { g_indirect_scale_pct = value; return 0; }
+  if (!strcmp(name, "indirect_depth1_off")) { g_indirect_depth1_off = value != 0; return 0; }
+  if (!strcmp(name, "draw_order")) { g_draw_order = value; return 0; }
   return -1;
 }
 
@@ -582,6 +596,8 @@ typedef struct {
   const OrcScene* sc;
   const TriBVH* bvh;
   OrcStats st;
+  int32_t maxDepth;     /* analysis: deepest payload.depth a radiance rtTrace of the current sample was issued with */
+  f3 lastRaw;           /* analysis: the last sample's colour before the per-sample clamp */
 } Ctx;
 
 /* rtPotentialIntersection restated with a deterministic equal-t rule
@@ -874,6 +890,7 @@ static void prog_disney(Ctx* cx, const OrcMaterial* m, f3 d, const Hit* h, Paylo
       normalOnLight = norm3(sub3(pointOnLight, ld3(light->position)));
     } else {
       float r1 = orc_rand(&p->randSeed); float r2 = orc_rand(&p->randSeed);
+      if (g_draw_order & 1) { float t_ = r1; r1 = r2; r2 = t_; }
       pointOnLight = add3(add3(ld3(light->position), scl3(ld3(light->u), r1)), scl3(ld3(light->v), r2));
       normalOnLight = norm3(ld3(light->normal));
     }
@@ -917,12 +934,15 @@ static void prog_disney(Ctx* cx, const OrcMaterial* m, f3 d, const Hit* h, Paylo
       indirect = divs3(mul3(brdf, c.color), pdf);
     }
   }
+  if (g_indirect_scale_pct != 100) indirect = scl3(indirect, (float)g_indirect_scale_pct * 0.01f);
+  if (g_indirect_depth1_off && p->depth == 1) indirect = mk3(0.f, 0.f, 0.f);
   p->color = add3(add3(indirect, direct), ld3(m->emission));
 }
 
 /* rtTrace for ray type 0: nearest hit -> closest-hit program; none -> miss.cu:10-12 */
 static void trace_radiance(Ctx* cx, f3 o, f3 d, float tmin, float tmax, Payload* pld) {
   Hit h;
+  if (pld->depth > cx->maxDepth) cx->maxDepth = pld->depth;
   if (!find_closest(cx, o, d, tmin, tmax, &h)) {
     cx->st.misses++;
     pld->color = mul3(pld->color, ld3(cx->sc->bgColor));
@@ -961,6 +981,7 @@ static f3 camera_sample(Ctx* cx, int32_t x, int32_t y, int32_t launchSeed) {
   f3 randInLens = scl3(rand_in_unit_disk(&pld.randSeed), cam->lensRadius);
   f3 offs = add3(scl3(ld3(cam->u), randInLens.x), scl3(ld3(cam->v), randInLens.y));
   float r1 = orc_rand(&pld.randSeed); float r2 = orc_rand(&pld.randSeed);
+  if (g_draw_order & 4) { float t_ = r1; r1 = r2; r2 = t_; }
   float xyx = ((float)x + r1 - 0.5f) / (float)sc->width;
   float xyy = ((float)y + r2 - 0.5f) / (float)sc->height;
   f3 org = add3(ld3(cam->origin), offs);
@@ -968,6 +989,7 @@ static f3 camera_sample(Ctx* cx, int32_t x, int32_t y, int32_t launchSeed) {
                                  scl3(ld3(cam->vertical), xyy)), ld3(cam->origin)), offs));
   cx->st.primaryRays++; cx->st.samples++;
   trace_radiance(cx, org, dir, sc->rayEpsilonT, ORC_RT_DEFAULT_MAX, &pld);
+  cx->lastRaw = pld.color;                                  /* analysis: the sample before Camera.cu:39 */
   return mk3(clampf(pld.color.x, 0.f, 1.f), clampf(pld.color.y, 0.f, 1.f), clampf(pld.color.z, 0.f, 1.f));
 }
 
@@ -987,6 +1009,76 @@ void orc_move_sphere(float c[3], float radius, float v[3], float time) {
     v[0] *= attenuationCoef; v[1] *= attenuationCoef; v[1] = -vend * attenuationCoef;
     time = time - t;
   }
+}
+
+/* ANALYSIS ONLY (DESIGN.md "coffee.png pin"): the reference's context has a 9608-byte OptiX stack (MinimalOptiX.cpp:134) and an
+ * exception program that adds badColor = (1,1,1) to the pixel INSTEAD of the sample (Exception.cu:10-12, MinimalOptiX.cpp:149-151)
+ * when the recursion overflows it.  At which nesting depth that happens is an OptiX 5.1 internal; this entry returns, per pixel,
+ * the sum of the clamped sample colours and the number of samples by the deepest radiance rtTrace of the sample
+ * (bucket k = depth k, k = 1..nBuckets-1; the last bucket collects everything deeper), so that
+ *   image(D) = (sum_{k<D} colour[k] + sum_{k>=D} count[k] * badColor) / spp
+ * can be formed for every candidate overflow depth D from one render.  colourSum: [H][W][nBuckets][3], count: [H][W][nBuckets]
+ * (only rows/columns of the region are written). */
+int orc_render_by_depth(const OrcScene* sc, const int32_t* seeds, int nSeeds, int x0, int y0, int x1, int y1,
+                        int nBuckets, float* colourSum, float* count) {
+  if (!sc || !colourSum || !count || nBuckets < 2) return -1;
+  if (x0 < 0 || y0 < 0 || x1 > sc->width || y1 > sc->height || x0 > x1 || y0 > y1) return -2;
+  TriBVH* bvh = (sc->nFaces > 0 && !sc->bruteForceTris) ? bvh_build(sc) : NULL;
+  const int rows = y1 - y0;
+#pragma omp parallel
+  {
+    Ctx cx; memset(&cx, 0, sizeof(cx)); cx.sc = sc; cx.bvh = bvh;
+#pragma omp for schedule(dynamic, 1)
+    for (int r = 0; r < rows; r++) {
+      int y = y0 + r;
+      for (int x = x0; x < x1; x++) {
+        const size_t px = (size_t)y * (size_t)sc->width + (size_t)x;
+        for (int s = 0; s < nSeeds; s++) {
+          cx.maxDepth = 0;
+          f3 c = camera_sample(&cx, x, y, seeds[s]);
+          int k = cx.maxDepth < nBuckets - 1 ? cx.maxDepth : nBuckets - 1;
+          float* cs = colourSum + 3 * (px * (size_t)nBuckets + (size_t)k);
+          cs[0] += c.x; cs[1] += c.y; cs[2] += c.z;
+          count[px * (size_t)nBuckets + (size_t)k] += 1.f;
+        }
+      }
+    }
+  }
+  bvh_free(bvh);
+  return 0;
+}
+
+/* ANALYSIS ONLY: what the per-sample clamp (Camera.cu:39) does in a region.  Per pixel and channel: the sum of the samples
+ * before the clamp (each capped at `cap` so that one firefly cannot own the mean), the number of samples above 1, and the
+ * sum of the clamped samples (= what orc_render accumulates).  Arrays are [H][W][3]. */
+int orc_render_clamp_stats(const OrcScene* sc, const int32_t* seeds, int nSeeds, int x0, int y0, int x1, int y1, float cap,
+                           float* rawSum, float* nClamped, float* clampedSum) {
+  if (!sc || !rawSum || !nClamped || !clampedSum) return -1;
+  if (x0 < 0 || y0 < 0 || x1 > sc->width || y1 > sc->height || x0 > x1 || y0 > y1) return -2;
+  TriBVH* bvh = (sc->nFaces > 0 && !sc->bruteForceTris) ? bvh_build(sc) : NULL;
+  const int rows = y1 - y0;
+#pragma omp parallel
+  {
+    Ctx cx; memset(&cx, 0, sizeof(cx)); cx.sc = sc; cx.bvh = bvh;
+#pragma omp for schedule(dynamic, 1)
+    for (int r = 0; r < rows; r++) {
+      int y = y0 + r;
+      for (int x = x0; x < x1; x++) {
+        const size_t px = 3 * ((size_t)y * (size_t)sc->width + (size_t)x);
+        for (int s = 0; s < nSeeds; s++) {
+          f3 c = camera_sample(&cx, x, y, seeds[s]);
+          const float raw[3] = { cx.lastRaw.x, cx.lastRaw.y, cx.lastRaw.z }, cl[3] = { c.x, c.y, c.z };
+          for (int k = 0; k < 3; k++) {
+            rawSum[px + k] += raw[k] < cap ? raw[k] : cap;      /* NaN compares false: counted as cap */
+            nClamped[px + k] += raw[k] > 1.f ? 1.f : 0.f;
+            clampedSum[px + k] += cl[k];
+          }
+        }
+      }
+    }
+  }
+  bvh_free(bvh);
+  return 0;
 }
 
 int orc_num_threads(void) {

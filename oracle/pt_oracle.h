@@ -128,6 +128,12 @@ int orc_closest_hit(const OrcScene* sc, const float org[3], const float dir[3],
                     float tmin, float tmax, float* tHit);
 /* "disney_binary64" = 1: evaluate disneySample/Pdf/Eval in binary64 (analysis only; see pt_oracle.c) */
 int orc_set_option(const char* name, int value);
+/* analysis: effect of the per-sample clamp (raw sums capped at `cap`, samples above 1, clamped sums; [H][W][3] each) */
+int orc_render_clamp_stats(const OrcScene* sc, const int32_t* seeds, int nSeeds, int x0, int y0, int x1, int y1, float cap,
+                           float* rawSum, float* nClamped, float* clampedSum);
+/* analysis: per-pixel sums of the clamped samples and sample counts by the deepest radiance rtTrace (see pt_oracle.c) */
+int orc_render_by_depth(const OrcScene* sc, const int32_t* seeds, int nSeeds, int x0, int y0, int x1, int y1,
+                        int nBuckets, float* colourSum, float* count);
 int orc_closest_hit_batch(const OrcScene* sc, const float* rays, int n, int32_t* outPrim, float* outT);
 
 /* ---- small pure functions exported for known-answer tests ---------------- */

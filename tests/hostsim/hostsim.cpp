@@ -253,6 +253,8 @@ struct LocalStack {
   int data[256];
   inline void store(int sp, int v) { data[sp] = v; }
   inline int load(int sp) const { return data[sp]; }
+  inline bool roomy(int) const { return true; }
+  inline void store_fast(int sp, int v) { data[sp] = v; }
 };
 
 struct HostScene {

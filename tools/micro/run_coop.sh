@@ -2,15 +2,13 @@ set -u
 export TMPDIR=/tmp
 ROOT=$(pwd)
 mkdir -p gpurun_out/r03c
-for w in 12 32; do for mb in 3.1 8.1; do ./tools/micro/gather_coop $mb $w; done; done 2>&1 | tee gpurun_out/r03c/coop.txt
-for mode in 0 1; do
+for w in 12 32; do ./tools/micro/gather_coop 3.1 $w; done 2>&1 | tee gpurun_out/r03c/coop.txt
+for mode in 0 3; do
  (cd /tmp && rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE --output-format csv -d $ROOT/gpurun_out/r03c/pmc$mode -- $ROOT/tools/micro/gather_coop 3.1 12 $mode > $ROOT/gpurun_out/r03c/pmc$mode.log 2>&1)
- (cd /tmp && rocprofv3 --kernel-trace --pmc TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum --output-format csv -d $ROOT/gpurun_out/r03c/pmcb$mode -- $ROOT/tools/micro/gather_coop 3.1 12 $mode > $ROOT/gpurun_out/r03c/pmcb$mode.log 2>&1)
- (cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $ROOT/gpurun_out/r03c/pmcc$mode -- $ROOT/tools/micro/gather_coop 3.1 12 $mode > $ROOT/gpurun_out/r03c/pmcc$mode.log 2>&1)
 done
 python3 - <<PY
 import csv, glob, collections
-for d in sorted(glob.glob("gpurun_out/r03c/pmc*/")):
+for d in sorted(glob.glob("gpurun_out/r03c/pmc[03]/")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(float); cnt = collections.Counter()
         for r in csv.DictReader(open(f)):
