@@ -18,7 +18,7 @@ BUILD    ?= build
 HIPFLAGS := $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -include cstring
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -mavx2 -mfma -Wall -Wno-unused-function -Wno-unknown-pragmas
 
-DEV_SRCS := $(CSRC)/moptix_api.hip $(CSRC)/megakernel.hip $(CSRC)/poolkernel.hip $(CSRC)/queuekernel.hip $(CSRC)/packetkernel.hip $(CSRC)/lbvh.hip
+DEV_SRCS := $(CSRC)/moptix_api.hip $(CSRC)/megakernel.hip $(CSRC)/queuekernel.hip $(CSRC)/packetkernel.hip $(CSRC)/lbvh.hip
 DEV_OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(DEV_SRCS))
 DEV_HDRS := $(wildcard $(CSRC)/*.h) include/moptix.h
 HOST_SRCS := $(HOST)/obj_loader.cpp $(HOST)/scene_file.cpp $(HOST)/scenes.cpp $(HOST)/standin_scenes.cpp $(HOST)/image_read.cpp $(HOST)/jpeg_read.cpp \
@@ -41,7 +41,7 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(DEV_HDRS)
 
 $(LIBDIR)/$(LIBNAME): $(DEV_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(DEV_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(DEV_OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 
 build/host_%.o: $(HOST)/%.cpp $(HOST_HDRS)
 	@mkdir -p build

@@ -221,6 +221,12 @@ class GpuFrame:
             self.ctxs.append(ctx2); self.accums.append(accum2)
         self.pending = [False] * len(self.ctxs)
         self.frame_no = 0
+        # the frame's collective runs behind the C ABI on the context's own RCCL communicator (moptix_gather_tiles /
+        # moptix_reduce_frame); MOPTIX_BENCH_FORCE_DIST=1 brings a one-rank communicator up on a 1-GPU box
+        self.use_comm = world > 1 or os.environ.get("MOPTIX_BENCH_FORCE_DIST") == "1"
+        if self.use_comm:
+            for c in self.ctxs:
+                D.comm_init(c, rank, world, self.device)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -235,11 +241,11 @@ class GpuFrame:
 
     def collect(self, j):                                               # the frame's one collective
         a = self.a
-        if self.world == 1:
+        if not self.use_comm:
             return None
         if self.sample_split:
-            return self.D.reduce_frame(self.accums[j], dst=0)
-        return self.D.gather_tiles(self.accums[j].view(a.height * a.width, 3), a.width, a.height, self.rank, self.world, dst=0)
+            return self.D.reduce_frame(self.accums[j], dst=0, ctx=self.ctxs[j])
+        return self.D.gather_tiles(self.accums[j].view(a.height * a.width, 3), a.width, a.height, self.rank, self.world, dst=0, ctx=self.ctxs[j])
 
     def _finish(self, j):                                               # frame in context j: wait for it, collect it
         if self.pending[j]:

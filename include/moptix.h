@@ -105,13 +105,14 @@ typedef struct moptix_stats {
   uint64_t analyticTests;        /* sphere/quad records tested (brute-force lists)        */
   uint64_t traversalSteps;       /* wave-level loop iterations (x64 lanes = lane slots)   */
   uint64_t activeLaneSteps;      /* lanes doing useful work summed over those iterations  */
-  uint64_t shadeBatches;         /* variant 1: shading/regeneration batches run            */
-  uint64_t shadeBatchLanes;      /* variant 1: slots processed by those batches            */
+  uint64_t shadeBatches;         /* shading / regeneration batches run (queue kernels)     */
+  uint64_t shadeBatchLanes;      /* slots processed by those batches                       */
 } moptix_stats;
 
 typedef struct moptix_accel_info {
   uint32_t nTriangles, nNodes, maxLeafSize, treeDepth;
-  float buildMs;                 /* device time of the last LBVH build (HIP events) */
+  float buildMs;                 /* wall time of the last acceleration build between two HIP events on the launch stream: its kernels plus the
+                                    host round trips between them (the binned-SAH builder reads one node count per level back) */
   uint64_t nodeBytes, triBytes;
 } moptix_accel_info;
 
@@ -154,8 +155,9 @@ int moptix_set_lights(moptix_context ctx, const moptix_light_params* lights, int
 int moptix_update_spheres(moptix_context ctx, int32_t first, const moptix_sphere_params* s, int32_t n);
 
 /* setAcceleration("NoAccel" | "Trbvh") (MinimalOptiX.cpp:248,378,494,534,748).
- * "Trbvh" -> Morton-code LBVH built on the device over all triangles; analytic
- * primitives always stay in brute-force lists. "NoAccel" with triangles present
+ * "Trbvh" -> built on the device over all triangles: Morton order, then (option "builder" = 1, the default) a binned
+ * surface-area-heuristic topology over that order, or (= 0) the Karras radix tree; four-wide 128-byte nodes either way.
+ * Analytic primitives always stay in brute-force lists. "NoAccel" with triangles present
  * is rejected (MOPTIX_ERR_INVALID). */
 int moptix_build_accel(moptix_context ctx, const char* kind);
 int moptix_get_accel_info(moptix_context ctx, moptix_accel_info* out);
@@ -180,8 +182,30 @@ int moptix_render_counted(moptix_context ctx, const int32_t* seeds, int32_t nSee
  * rotates from group to group so that no rank owns whole columns).  Default (0,1) = whole frame. */
 int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
 
+/* Multi-GPU collectives (new; SURVEY 8e, north_star "RCCL gather over xGMI"): one process per GPU, the context owns an
+ * RCCL communicator.  One rank calls moptix_comm_unique_id (ncclGetUniqueId) and hands the 128 bytes to the others by
+ * whatever the host has (a file, MPI, torch.distributed, a socket); every rank then calls moptix_comm_init
+ * (ncclCommInitRank: collective, blocks until all nRanks have called it).
+ *   moptix_gather_tiles : tile split (moptix_set_partition(rank, nRanks) as the communicator's) -- every other rank packs its
+ *                         tiles and ncclSend()s them to dstRank, which receives them in one group and writes them into its
+ *                         accuBuffer on the device: dstRank then holds the whole frame, bit-identical to a one-GPU render.
+ *   moptix_reduce_frame : sample split -- ncclReduce(sum) of the accuBuffers into dstRank's.
+ * Both block until the data has landed (stream-synchronised).  With a communicator of one rank they are no-ops.
+ * moptix_pack_tiles / moptix_unpack_tiles are the device-side halves of the gather (rank r's tiles of the accuBuffer <->
+ * a dense buffer of moptix_packed_tile_floats(nRanks) floats in work-item order), exposed so that the partition can be
+ * tested on one GPU. */
+#define MOPTIX_COMM_ID_BYTES 128
+int moptix_comm_unique_id(uint8_t* id128);
+int moptix_comm_init(moptix_context ctx, const uint8_t* id128, int32_t rank, int32_t nRanks);
+int moptix_comm_destroy(moptix_context ctx);
+int moptix_gather_tiles(moptix_context ctx, int32_t dstRank);
+int moptix_reduce_frame(moptix_context ctx, int32_t dstRank);
+int moptix_packed_tile_floats(moptix_context ctx, int32_t nRanks, uint64_t* outFloats);
+int moptix_pack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, float* dstDevice);
+int moptix_unpack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, const float* srcDevice);
+
 /* tuning knobs (none of them changes a bit of the image):
- *   "kernel_variant"   0 per-lane kernel, 1 per-wave pool, 2 slot queues per wave, 3 slot queues per workgroup,
+ *   "kernel_variant"   0 per-lane kernel, 3 path slots and queues shared by the workgroup (variants 1 and 2 of rounds 1-2 are gone),
  *                      4 = 3 with one shading visit per bounce (pt_packet.h; scenes with <= 3 lights, else 3 runs).
  *                      While it has not been set: 4 for launches of >= 1e6 samples and >= 16 seeds on scenes that are not
  *                      mostly glass ("auto_packet" = 0 turns that off), else 3; scenes without triangles: see "analytic_queue"
@@ -198,8 +222,8 @@ int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
  *                      2 = as 1 with one pixel's samples per wave, 3 = all samples of a pixel back to back, pixels with
  *                      the deepest paths of earlier launches first (default)
  *   "blocks_per_cu"    resident workgroups per CU (default 3)
- *   "swap_lanes", "starve_lanes"   node-loop swap / starvation thresholds of variants 2, 3 and 4
- *   "exit_threshold" (variant 0), "pool_slots" (128|192|256), "refill_lanes", "leaf_threshold" (variant 1)
+ *   "swap_lanes", "starve_lanes"   node-loop swap / starvation thresholds of variants 3 and 4
+ *   "exit_threshold", "leaf_threshold" (variant 0)
  *   "sample_buffer_mb" budget of the per-sample buffer (default 16384); larger batches run in passes
  *   "fast_shading"     0 (default): disneyPdf / disneyEval in correctly rounded binary32, bit-parity with the oracle;
  *                      1: hardware reciprocal / square-root approximations there (the reference itself is built with

@@ -109,6 +109,8 @@ DEVICE_SYMBOLS = [
     "moptix_render_counted", "moptix_set_partition", "moptix_set_option", "moptix_get_option",
     "moptix_accum_read", "moptix_accum_clear", "moptix_accum_device_ptr", "moptix_accum_bind",
     "moptix_resolve_rgb8", "moptix_kernel_time", "moptix_reduce_time", "moptix_debug_read_accel", "moptix_debug_trace",
+    "moptix_comm_unique_id", "moptix_comm_init", "moptix_comm_destroy", "moptix_gather_tiles", "moptix_reduce_frame",
+    "moptix_packed_tile_floats", "moptix_pack_tiles", "moptix_unpack_tiles",
 ]
 HOST_SYMBOLS = [
     "mohost_last_error", "mohost_scene_build", "mohost_scene_free", "mohost_scene_get_sizes",
@@ -169,6 +171,15 @@ def device_lib():
         L.moptix_reduce_time.argtypes = [vp, C.POINTER(C.c_double)]
         L.moptix_debug_read_accel.argtypes = [vp, vp, vp, i32p]
         L.moptix_debug_trace.argtypes = [vp, f32p, i32, f32p, i32p]
+        u8p = C.POINTER(C.c_uint8)
+        L.moptix_comm_unique_id.argtypes = [u8p]
+        L.moptix_comm_init.argtypes = [vp, u8p, i32, i32]
+        L.moptix_comm_destroy.argtypes = [vp]
+        L.moptix_gather_tiles.argtypes = [vp, i32]
+        L.moptix_reduce_frame.argtypes = [vp, i32]
+        L.moptix_packed_tile_floats.argtypes = [vp, i32, C.POINTER(C.c_uint64)]
+        L.moptix_pack_tiles.argtypes = [vp, i32, i32, vp]
+        L.moptix_unpack_tiles.argtypes = [vp, i32, i32, vp]
         _dev = L
     return _dev
 

@@ -282,6 +282,42 @@ class Context:
         self._chk(self._L.moptix_reduce_time(self._h, C.byref(ms)))
         return ms.value
 
+    # ---- multi-GPU collectives on RCCL, behind the C ABI (include/moptix.h "Multi-GPU collectives") ----
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId as 128 bytes: made by one rank, handed to the others by the host (bench.py: torch.distributed)."""
+        buf = (C.c_uint8 * 128)()
+        rc = K.device_lib().moptix_comm_unique_id(buf)
+        if rc != K.MOPTIX_OK:
+            raise MoptixError(rc, K.device_lib().moptix_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self._L.moptix_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def comm_destroy(self):
+        self._chk(self._L.moptix_comm_destroy(self._h))
+
+    def gather_tiles(self, dst=0):
+        """Tile split: every rank's tiles into rank dst's accuBuffer (grouped ncclSend / ncclRecv + unpack on the device)."""
+        self._chk(self._L.moptix_gather_tiles(self._h, int(dst)))
+
+    def reduce_frame(self, dst=0):
+        """Sample split: ncclReduce(sum) of the accuBuffers into rank dst's."""
+        self._chk(self._L.moptix_reduce_frame(self._h, int(dst)))
+
+    def packed_tile_floats(self, nranks):
+        n = C.c_uint64()
+        self._chk(self._L.moptix_packed_tile_floats(self._h, int(nranks), C.byref(n)))
+        return int(n.value)
+
+    def pack_tiles(self, rank, nranks, dst_device_ptr):
+        self._chk(self._L.moptix_pack_tiles(self._h, int(rank), int(nranks), C.c_void_p(dst_device_ptr)))
+
+    def unpack_tiles(self, rank, nranks, src_device_ptr):
+        self._chk(self._L.moptix_unpack_tiles(self._h, int(rank), int(nranks), C.c_void_p(src_device_ptr)))
+
     def debug_read_accel(self):
         a = self.accel_info()
         nodes = np.zeros((max(1, a.nNodes), 32), np.uint32)     # Node128 = 32 words

@@ -18,11 +18,9 @@ struct LaunchArgs {
   int leafThreshold;                // run the leaf pass once this many lanes are parked at a leaf
   int* stackOverflow;               // per-thread spill area for trees deeper than the LDS stack (or null)
   unsigned long long* counters;     // 16 x u64 (counting build only)
-  // variant 1 (poolkernel.hip)
-  void* poolCold;                   // per-wave slot records in HBM
-  int refillLanes;                  // refill from Q_TRAV once this many lanes are idle
-  int starveLanes;                  // shade a partial batch once this many lanes idle and Q_TRAV is empty
-  // variant 2 (queuekernel.hip)
+  // variants 3 and 4 (queuekernel.hip, packetkernel.hip)
+  void* poolCold;                   // path-slot records in HBM
+  int starveLanes;                  // run a partial batch once this many lanes of the wave have nothing to traverse
   int swapLanes;                    // leave the node loop once this many lanes stand at a leaf / have finished
   int ovfDepth;                     // ints of stack overflow per slot
   int slotsInUse;                   // path slots per pool a launch uses (0 = all); fewer slots = shorter critical path
@@ -81,14 +79,11 @@ __device__ __forceinline__ void store_sample(const LaunchArgs& a, int item, v3 v
 int megakernel_lds_stack_entries();
 hipError_t launch_reduce_samples(hipStream_t stream, const LaunchArgs& a);
 hipError_t launch_megakernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted);
-int poolkernel_lds_stack_entries();
-size_t poolkernel_cold_bytes(int nBlocks, int poolSlots);
-hipError_t launch_poolkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, int poolSlots, bool counted);
 int queuekernel_lds_stack_entries();
 int queuekernel_slots();
 size_t queuekernel_cold_bytes(int nBlocks);
 size_t queuekernel_overflow_ints(int nBlocks, int ovfDepth);
-hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool shared, bool counted, bool fastShading);
+hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading);
 int packetkernel_lds_stack_entries();
 size_t packetkernel_cold_bytes(int nBlocks);
 size_t packetkernel_overflow_ints(int nBlocks, int ovfDepth);

@@ -2,6 +2,7 @@
 // Host-side staging of the scene, upload, LBVH build, launches, read-back, measurement.
 // There is no CPU path: every entry point that computes needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
@@ -76,7 +77,7 @@ struct moptix_context_t {
   int optTileMajor = 3;              // all samples of a pixel back to back, pixels with the deepest paths of earlier launches first
   long long tileHistoryTiles = -1;
   DevBuf<unsigned int> dTileCost, dTileCostSorted; DevBuf<int> dTileOrder, dTileIota; DevBuf<uint8_t> dSortTmp;
-  int optPoolSlots = 128, optRefillLanes = 16, optStarveLanes = 16, optSampleBufMB = 16384, optLeafThreshold = 16, optSwapLanes = 32;
+  int optStarveLanes = 16, optSampleBufMB = 16384, optLeafThreshold = 16, optSwapLanes = 32;
   unsigned long long lastExtra[5] = { 0, 0, 0, 0, 0 };
 
   std::vector<int> seedStaging;
@@ -91,6 +92,9 @@ struct moptix_context_t {
   int optAuxDepth = 16;              // variant 4: depth from which a path's shadow rays get slots of their own (0 = off)
   double kernelMs = 0.0, reduceMs = 0.0; uint64_t nLaunches = 0;
   bool asyncPending = false;
+  // multi-GPU (one process per GPU): RCCL communicator of this rank + staging for the tile gather
+  ncclComm_t comm = nullptr; int commRank = 0, commRanks = 1;
+  DevBuf<float> dTileSend, dTileRecv;
 };
 
 namespace {
@@ -211,7 +215,6 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   perPass = std::max(1LL, std::min(perPass, (long long)nSeeds));
 
   const bool hasTris = a.scene.rootRef != kEmptyRef;
-  const bool usePool = c->optVariant == 1 && hasTris;
   // Scenes without triangles ("NoAccel"): the per-lane kernel, or ("analytic_queue" = 1) the queue kernel, where every ray
   // is finished by the brute-force lists at set-up, inside a full 64-lane batch, and the slots cycle through the batches.
   // With the lists read by scalar loads, four spheres per trip (pt_path.h trav_begin): random_spheres (497 + 33 primitives)
@@ -229,9 +232,9 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   // BASELINE config 5: 257 ms on variant 3, 283 on variant 4 at 64 spp) gets nothing from the packet and pays for its wider records
   const bool autoPacket = nSamples >= 1.0e6 && nSeeds >= 16 && c->glassFaceShare <= 0.5;
   const bool usePacket = packetOk && (c->optVariant == 4 || (!c->variantExplicit && c->optAutoPacket != 0 && autoPacket));
-  const bool useQueue = !usePacket && (c->optVariant >= 2) && (hasTris || analyticQueue);
-  c->lastVariant = usePacket ? 4 : useQueue ? (c->optVariant == 2 ? 2 : 3) : usePool ? 1 : 0;
-  a.refillLanes = c->optRefillLanes; a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;
+  const bool useQueue = !usePacket && (c->optVariant >= 3) && (hasTris || analyticQueue);
+  c->lastVariant = usePacket ? 4 : useQueue ? 3 : 0;
+  a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;
   // Slots without a path are what deep paths borrow for their shadow rays (packetkernel.hip, "aux_depth"); once the work
   // items run out there are plenty, before that only the ones kept free here.  A launch under 1e8 samples (an 8-way share
   // of the benchmark frame) is short enough for its tail to matter more than the throughput of 64 more paths per pool:
@@ -256,15 +259,11 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     HIPCHK(c, c->dPoolCold.ensure(queuekernel_cold_bytes(nBlocks)), "alloc path pool");
     a.poolCold = c->dPoolCold.p;
   } else {
-    const int ldsStack = usePool ? poolkernel_lds_stack_entries() : megakernel_lds_stack_entries();
+    const int ldsStack = megakernel_lds_stack_entries();
     if (c->bvh.stackBound > ldsStack) {
       const size_t need = (size_t)(c->bvh.stackBound - ldsStack + 1) * nBlocks * 256;
       HIPCHK(c, c->dOverflow.ensure(need), "alloc stack overflow area");
       a.stackOverflow = c->dOverflow.p;
-    }
-    if (usePool) {
-      HIPCHK(c, c->dPoolCold.ensure(poolkernel_cold_bytes(nBlocks, c->optPoolSlots)), "alloc path pool");
-      a.poolCold = c->dPoolCold.p;
     }
   }
   HIPCHK(c, c->dSampleBuf.ensure((size_t)perPass * a.nItems * 3), "alloc per-sample buffer");
@@ -314,8 +313,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
     if (usePacket) HIPCHK(c, launch_packetkernel(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch packet megakernel");
-    else if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, c->optVariant != 2, counted, c->optFastShading != 0), "launch queue megakernel");
-    else if (usePool) HIPCHK(c, launch_poolkernel(c->stream, a, nBlocks, c->optPoolSlots, counted), "launch pool megakernel");
+    else if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch queue megakernel");
     else HIPCHK(c, launch_megakernel(c->stream, a, nBlocks, counted), "launch megakernel");
     HIPCHK(c, hipEventRecord(c->ev1, c->stream), "event");
     HIPCHK(c, launch_reduce_samples(c->stream, a), "launch sample reduction");
@@ -339,6 +337,44 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   if (blocking && counted && stats) return read_stats(c, stats);
   return MOPTIX_OK;
 }
+
+// ---- tile split: a rank's tiles <-> a dense buffer (work-item order of megakernel.h item_to_pixel) ----
+struct TileDeal { int nItems, tilesX, rank, nRanks, width, height; };
+__device__ __forceinline__ bool deal_pixel(const TileDeal& d, int i, int& pixel) {
+  const int lt = i >> 6, in = i & 63;
+  const int gt = lt * d.nRanks + (d.rank + lt) % d.nRanks;
+  const int tx = gt % d.tilesX, ty = gt / d.tilesX;
+  const int x = tx * 8 + (in & 7), y = ty * 8 + (in >> 3);
+  pixel = y * d.width + x;
+  return (x < d.width) & (y < d.height);
+}
+__global__ void __launch_bounds__(256) k_pack_tiles(const float* __restrict__ accum, float* __restrict__ packed, TileDeal d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= d.nItems) return;
+  int px; float r = 0.f, g = 0.f, b = 0.f;
+  if (deal_pixel(d, i, px)) { r = accum[3 * (size_t)px]; g = accum[3 * (size_t)px + 1]; b = accum[3 * (size_t)px + 2]; }
+  packed[3 * (size_t)i] = r; packed[3 * (size_t)i + 1] = g; packed[3 * (size_t)i + 2] = b;
+}
+__global__ void __launch_bounds__(256) k_unpack_tiles(const float* __restrict__ packed, float* __restrict__ accum, TileDeal d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= d.nItems) return;
+  int px;
+  if (deal_pixel(d, i, px)) { accum[3 * (size_t)px] = packed[3 * (size_t)i]; accum[3 * (size_t)px + 1] = packed[3 * (size_t)i + 1]; accum[3 * (size_t)px + 2] = packed[3 * (size_t)i + 2]; }
+}
+int tile_deal(moptix_context c, int rank, int nRanks, TileDeal& d) {
+  if (!c->haveParams) return fail(c, MOPTIX_ERR_STATE, "no params");
+  if (nRanks < 1 || rank < 0 || rank >= nRanks) return fail(c, MOPTIX_ERR_INVALID, "bad partition");
+  const int tilesX = ((int)c->params.width + 7) / 8, tilesY = ((int)c->params.height + 7) / 8;
+  const long long localTiles = ((long long)tilesX * tilesY + nRanks - 1) / nRanks;
+  if (localTiles * 64 > 0x7fffffffLL) return fail(c, MOPTIX_ERR_LIMIT, "frame too large");
+  d.nItems = (int)(localTiles * 64); d.tilesX = tilesX; d.rank = rank; d.nRanks = nRanks;
+  d.width = (int)c->params.width; d.height = (int)c->params.height;
+  return MOPTIX_OK;
+}
+int ncclFail(moptix_context c, ncclResult_t r, const char* what) {
+  return fail(c, MOPTIX_ERR_HIP, std::string(what) + ": " + ncclGetErrorString(r));
+}
+#define NCCLCHK(c, x, what) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return ncclFail((c), r_, (what)); } while (0)
 
 }  // namespace
 
@@ -386,6 +422,8 @@ int moptix_destroy(moptix_context c) {
   c->dPoolCold.release(); c->dSampleBuf.release();
   c->dTileCost.release(); c->dTileCostSorted.release(); c->dTileOrder.release(); c->dTileIota.release(); c->dSortTmp.release();
   c->dAccum.release(); c->dSeeds.release(); c->dWork.release(); c->dCounters.release(); c->dOverflow.release(); c->dRgb8.release();
+  c->dTileSend.release(); c->dTileRecv.release();
+  if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -622,12 +660,10 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   if (!strcmp(name, "exit_threshold")) { if (value < 0 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "exit_threshold in [0,64]"); c->optExitThreshold = value; }
   else if (!strcmp(name, "leaf_size")) { if (value < 1 || value > kMaxLeaf) return fail(c, MOPTIX_ERR_INVALID, "leaf_size in [1,8]"); if (value != c->optLeafSize) c->accelBuilt = false; c->optLeafSize = value; }
   else if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) return fail(c, MOPTIX_ERR_INVALID, "blocks_per_cu in [1,8]"); c->optBlocksPerCU = value; }
-  else if (!strcmp(name, "kernel_variant")) { if (value < 0 || value > 4) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {0,1,2,3,4}"); c->optVariant = value; c->variantExplicit = true; }
-  else if (!strcmp(name, "pool_slots")) { if (value != 128 && value != 192 && value != 256) return fail(c, MOPTIX_ERR_INVALID, "pool_slots in {128,192,256}"); c->optPoolSlots = value; }
+  else if (!strcmp(name, "kernel_variant")) { if (value != 0 && value != 3 && value != 4) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {0,3,4} (1 and 2 were removed in round 3)"); c->optVariant = value; c->variantExplicit = true; }
   else if (!strcmp(name, "sample_buffer_mb")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "sample_buffer_mb >= 1"); c->optSampleBufMB = value; }
   else if (!strcmp(name, "leaf_threshold")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "leaf_threshold in [1,64]"); c->optLeafThreshold = value; }
   else if (!strcmp(name, "swap_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "swap_lanes in [1,64]"); c->optSwapLanes = value; }
-  else if (!strcmp(name, "refill_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "refill_lanes in [1,64]"); c->optRefillLanes = value; }
   else if (!strcmp(name, "starve_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "starve_lanes in [1,64]"); c->optStarveLanes = value; }
   else if (!strcmp(name, "tile_major")) { if (value < 0 || value > 3) return fail(c, MOPTIX_ERR_INVALID, "tile_major in {0,1,2,3}"); c->optTileMajor = value; }
   else if (!strcmp(name, "auto_packet")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "auto_packet in {0,1}"); c->optAutoPacket = value; }
@@ -647,11 +683,9 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "leaf_size")) *value = c->optLeafSize;
   else if (!strcmp(name, "blocks_per_cu")) *value = c->optBlocksPerCU;
   else if (!strcmp(name, "kernel_variant")) *value = c->optVariant;
-  else if (!strcmp(name, "pool_slots")) *value = c->optPoolSlots;
   else if (!strcmp(name, "sample_buffer_mb")) *value = c->optSampleBufMB;
   else if (!strcmp(name, "leaf_threshold")) *value = c->optLeafThreshold;
   else if (!strcmp(name, "swap_lanes")) *value = c->optSwapLanes;
-  else if (!strcmp(name, "refill_lanes")) *value = c->optRefillLanes;
   else if (!strcmp(name, "starve_lanes")) *value = c->optStarveLanes;
   else if (!strcmp(name, "tile_major")) *value = c->optTileMajor;
   else if (!strcmp(name, "watchdog_ms")) *value = c->optWatchdogMs;
@@ -774,6 +808,118 @@ int moptix_debug_trace(moptix_context c, const float* rays, int32_t n, float* ou
   if (dP) (void)hipFree(dP);
   if (dOvf) (void)hipFree(dOvf);
   if (e != hipSuccess) return hipFail(c, e, "debug trace");
+  return MOPTIX_OK;
+}
+
+// ---- multi-GPU collectives: one process per GPU, RCCL over xGMI ---------------------------------
+
+int moptix_comm_unique_id(uint8_t* id128) {
+  if (!id128) return fail(nullptr, MOPTIX_ERR_INVALID, "null id");
+  static_assert(sizeof(ncclUniqueId) == MOPTIX_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return ncclFail(nullptr, r, "ncclGetUniqueId");
+  memcpy(id128, &id, sizeof(id));
+  return MOPTIX_OK;
+}
+
+int moptix_comm_init(moptix_context c, const uint8_t* id128, int32_t rank, int32_t nRanks) {
+  if (!c || !id128 || nRanks < 1 || rank < 0 || rank >= nRanks) return fail(c, MOPTIX_ERR_INVALID, "bad communicator arguments");
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+  ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+  NCCLCHK(c, ncclCommInitRank(&c->comm, nRanks, id, rank), "ncclCommInitRank");
+  c->commRank = rank; c->commRanks = nRanks;
+  return MOPTIX_OK;
+}
+
+int moptix_comm_destroy(moptix_context c) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  if (c->comm) { HIPCHK(c, hipSetDevice(c->device), "hipSetDevice"); (void)hipStreamSynchronize(c->stream); NCCLCHK(c, ncclCommDestroy(c->comm), "ncclCommDestroy"); c->comm = nullptr; }
+  c->commRank = 0; c->commRanks = 1;
+  return MOPTIX_OK;
+}
+
+int moptix_packed_tile_floats(moptix_context c, int32_t nRanks, uint64_t* out) {
+  if (!c || !out) return MOPTIX_ERR_INVALID;
+  TileDeal d; int rc = tile_deal(c, 0, nRanks, d);
+  if (rc != MOPTIX_OK) return rc;
+  *out = 3ull * (uint64_t)d.nItems;
+  return MOPTIX_OK;
+}
+
+int moptix_pack_tiles(moptix_context c, int32_t rank, int32_t nRanks, float* dstDevice) {
+  if (!c || !dstDevice) return fail(c, MOPTIX_ERR_INVALID, "null argument");
+  TileDeal d; int rc = tile_deal(c, rank, nRanks, d);
+  if (rc != MOPTIX_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  if ((rc = ensure_accum(c)) != MOPTIX_OK) return rc;
+  k_pack_tiles<<<dim3((d.nItems + 255) / 256), dim3(256), 0, c->stream>>>(accum_ptr(c), dstDevice, d);
+  HIPCHK(c, hipGetLastError(), "pack tiles");
+  HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+  return MOPTIX_OK;
+}
+
+int moptix_unpack_tiles(moptix_context c, int32_t rank, int32_t nRanks, const float* srcDevice) {
+  if (!c || !srcDevice) return fail(c, MOPTIX_ERR_INVALID, "null argument");
+  TileDeal d; int rc = tile_deal(c, rank, nRanks, d);
+  if (rc != MOPTIX_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  if ((rc = ensure_accum(c)) != MOPTIX_OK) return rc;
+  k_unpack_tiles<<<dim3((d.nItems + 255) / 256), dim3(256), 0, c->stream>>>(srcDevice, accum_ptr(c), d);
+  HIPCHK(c, hipGetLastError(), "unpack tiles");
+  HIPCHK(c, hipStreamSynchronize(c->stream), "sync");
+  return MOPTIX_OK;
+}
+
+int moptix_gather_tiles(moptix_context c, int32_t dstRank) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  if (!c->comm) return fail(c, MOPTIX_ERR_STATE, "moptix_comm_init has not been called");
+  if (c->nRanks != c->commRanks || c->rank != c->commRank) return fail(c, MOPTIX_ERR_STATE, "moptix_set_partition does not match the communicator's rank / size");
+  if (dstRank < 0 || dstRank >= c->commRanks) return fail(c, MOPTIX_ERR_INVALID, "bad destination rank");
+  int rc = moptix_sync(c);
+  if (rc != MOPTIX_OK) return rc;
+  TileDeal d;
+  if ((rc = tile_deal(c, c->rank, c->nRanks, d)) != MOPTIX_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  if ((rc = ensure_accum(c)) != MOPTIX_OK) return rc;
+  const size_t cnt = 3 * (size_t)d.nItems;                   // the same on every rank: whole groups of nRanks tiles
+  const int n = c->commRanks;
+  if (n == 1) return MOPTIX_OK;                              // the frame is already in place
+  const dim3 grid((d.nItems + 255) / 256), block(256);
+  if (c->rank != dstRank) {
+    HIPCHK(c, c->dTileSend.ensure(cnt), "alloc tile staging");
+    k_pack_tiles<<<grid, block, 0, c->stream>>>(accum_ptr(c), c->dTileSend.p, d);
+    HIPCHK(c, hipGetLastError(), "pack tiles");
+    NCCLCHK(c, ncclSend(c->dTileSend.p, cnt, ncclFloat, dstRank, c->comm, c->stream), "ncclSend");
+  } else {
+    HIPCHK(c, c->dTileRecv.ensure(cnt * (size_t)n), "alloc tile staging");
+    NCCLCHK(c, ncclGroupStart(), "ncclGroupStart");
+    for (int r = 0; r < n; r++)
+      if (r != dstRank) NCCLCHK(c, ncclRecv(c->dTileRecv.p + cnt * (size_t)r, cnt, ncclFloat, r, c->comm, c->stream), "ncclRecv");
+    NCCLCHK(c, ncclGroupEnd(), "ncclGroupEnd");
+    for (int r = 0; r < n; r++) {                            // the other ranks' tiles into this rank's accuBuffer
+      if (r == dstRank) continue;
+      TileDeal dr = d; dr.rank = r;
+      k_unpack_tiles<<<grid, block, 0, c->stream>>>(c->dTileRecv.p + cnt * (size_t)r, accum_ptr(c), dr);
+    }
+    HIPCHK(c, hipGetLastError(), "unpack tiles");
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream), "sync after gather");
+  return MOPTIX_OK;
+}
+
+int moptix_reduce_frame(moptix_context c, int32_t dstRank) {
+  if (!c) return MOPTIX_ERR_INVALID;
+  if (!c->comm) return fail(c, MOPTIX_ERR_STATE, "moptix_comm_init has not been called");
+  if (dstRank < 0 || dstRank >= c->commRanks) return fail(c, MOPTIX_ERR_INVALID, "bad destination rank");
+  int rc = moptix_sync(c);
+  if (rc != MOPTIX_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  if ((rc = ensure_accum(c)) != MOPTIX_OK) return rc;
+  if (c->commRanks > 1)
+    NCCLCHK(c, ncclReduce(accum_ptr(c), accum_ptr(c), 3 * c->accumPixels, ncclFloat, ncclSum, dstRank, c->comm, c->stream), "ncclReduce");
+  HIPCHK(c, hipStreamSynchronize(c->stream), "sync after reduce");
   return MOPTIX_OK;
 }
 

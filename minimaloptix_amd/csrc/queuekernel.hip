@@ -18,7 +18,7 @@
 // wave-level ray compaction + sorting by stage of the north star; the per-path arithmetic is the
 // same pt_path.h code as variants 0/1, so the images are bit-identical.
 //
-//   variant 2 (SHARED = false): every wave has its own 128 slots and queues (wave-synchronous).
+//   (SHARED = false, every wave with its own 128 slots and queues, was variant 2 of rounds 1-2; it is no longer instantiated)
 //   variant 3 (SHARED = true):  the 4 waves of a workgroup share 512 slots and one set of queues
 //       (a spin-lock in LDS guards one short queue transaction per pass), so that full batches
 //       of every stage are available almost all the time.
@@ -628,17 +628,14 @@ int queuekernel_slots() { return kP; }
 size_t queuekernel_cold_bytes(int nBlocks) { return (size_t)nBlocks * kWaves * kP * sizeof(SlotCold); }
 size_t queuekernel_overflow_ints(int nBlocks, int ovfDepth) { return (size_t)nBlocks * kWaves * kP * (size_t)ovfDepth; }
 
-hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool shared, bool counted, bool fastShading) {
+hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading) {
   dim3 grid(nBlocks), block(kBlockThreads);
-  if (shared && fastShading) {       // opt-in approximate BRDF arithmetic (pt_disney.h ShadeMath); default variant only
+  if (fastShading) {       // opt-in approximate BRDF arithmetic (pt_disney.h ShadeMath); default variant only
     if (counted) pt_queuekernel<true, true, true><<<grid, block, 0, stream>>>(a);
     else         pt_queuekernel<false, true, true><<<grid, block, 0, stream>>>(a);
-  } else if (shared) {
+  } else {
     if (counted) pt_queuekernel<true, true><<<grid, block, 0, stream>>>(a);
     else         pt_queuekernel<false, true><<<grid, block, 0, stream>>>(a);
-  } else {
-    if (counted) pt_queuekernel<true, false><<<grid, block, 0, stream>>>(a);
-    else         pt_queuekernel<false, false><<<grid, block, 0, stream>>>(a);
   }
   return hipGetLastError();
 }

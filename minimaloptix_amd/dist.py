@@ -54,12 +54,33 @@ def _tile_plan(width, height, rank, nranks, dst, device):
     return plan
 
 
-def gather_tiles(accum, width, height, rank, nranks, dst=0, group=None):
+def comm_init(ctx, rank, nranks, device):
+    """RCCL communicator of a minimaloptix_amd.Context (C ABI moptix_comm_init): rank 0 makes the ncclUniqueId, the
+    process group that is already up (torch.distributed) carries its 128 bytes to the other ranks."""
+    import torch
+    import torch.distributed as dist
+    buf = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == 0:
+        buf.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+    if nranks > 1:
+        dist.broadcast(buf, src=0)
+    ctx.comm_init(bytes(buf.cpu().numpy().tobytes()), rank, nranks)
+
+
+def gather_tiles(accum, width, height, rank, nranks, dst=0, group=None, ctx=None):
     """accum: torch tensor [H*W, 3] (or [H, W, 3]) holding this rank's tiles (others untouched).
-    Returns the assembled [H, W, 3] frame on `dst`, None elsewhere.  One collective: gather to `dst`."""
+    Returns the assembled [H, W, 3] frame on `dst`, None elsewhere.  One collective: gather to `dst`.
+
+    With `ctx` (a Context whose accuBuffer `accum` is and whose communicator is up, comm_init above) the exchange is the
+    C ABI's moptix_gather_tiles: pack kernel, grouped ncclSend / ncclRecv over RCCL, unpack kernel -- nothing in Python
+    touches the pixels.  Without it (CPU tensors: the gloo tests of the partition logic) the same packed layout goes
+    through torch.distributed.gather."""
     import torch
     import torch.distributed as dist
     flat = accum.reshape(-1, 3)
+    if ctx is not None:
+        ctx.gather_tiles(dst)
+        return flat.reshape(height, width, 3) if rank == dst else None
     if nranks == 1:
         return flat.reshape(height, width, 3)
     plan = _tile_plan(width, height, rank, nranks, dst, flat.device)
@@ -80,8 +101,11 @@ def sample_split_seeds(seeds, rank, nranks):
     return np.asarray(seeds)[rank::nranks]
 
 
-def reduce_frame(accum, dst=0, group=None):
-    """Sample split: sum of the per-rank accumulators on `dst`."""
+def reduce_frame(accum, dst=0, group=None, ctx=None):
+    """Sample split: sum of the per-rank accumulators on `dst` (with `ctx`: the C ABI's moptix_reduce_frame = ncclReduce)."""
+    if ctx is not None:
+        ctx.reduce_frame(dst)
+        return accum
     import torch.distributed as dist
     dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return accum

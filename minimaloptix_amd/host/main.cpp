@@ -5,6 +5,10 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <vector>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "minimal_optix.h"
 
@@ -12,13 +16,17 @@ static void usage() {
   fprintf(stderr,
           "usage: moptix_render [--scene spheres|coffee|cornell_quads|random_spheres|random_spheres_256|dining_standin|million_standin|coffee_pot_standin|<file scene>]\n"
           "                     [--spp N] [--width W] [--height H] [--seed S] [--scenes DIR/] [--out PREFIX] [--outdir DIR]\n"
-          "                     [--autosave] [--device D] [--random-seeds] [--strict-missing]\n");
+          "                     [--autosave] [--device D] [--random-seeds] [--strict-missing]\n"
+          "       multi-GPU (one process per GPU, tile split + RCCL gather to rank 0, which writes the image):\n"
+          "                     [--spawn N]  start N ranks of this program, rank r on device r, and wait for them\n"
+          "                     [--rank R --ranks N --comm-file PATH]  one rank of a job started by something else\n");
 }
 
 int main(int argc, char** argv) {
   std::string scene = "spheres", prefix = "frame", scenes = "scenes/", outdir = ".";
   unsigned spp = 32, width = 1920, height = 1080, seed = 0;
   int device = 0; bool autosave = false, randomSeeds = false, strict = false;
+  int rank = 0, ranks = 1, spawn = 0; std::string commFile;
   for (int i = 1; i < argc; i++) {
     auto need = [&](const char* n) { if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", n); exit(2); } return argv[++i]; };
     if (!strcmp(argv[i], "--scene")) scene = need("--scene");
@@ -30,13 +38,38 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--out")) prefix = need("--out");
     else if (!strcmp(argv[i], "--outdir")) outdir = need("--outdir");
     else if (!strcmp(argv[i], "--device")) device = atoi(need("--device"));
+    else if (!strcmp(argv[i], "--rank")) rank = atoi(need("--rank"));
+    else if (!strcmp(argv[i], "--ranks")) ranks = atoi(need("--ranks"));
+    else if (!strcmp(argv[i], "--comm-file")) commFile = need("--comm-file");
+    else if (!strcmp(argv[i], "--spawn")) spawn = atoi(need("--spawn"));
     else if (!strcmp(argv[i], "--autosave")) autosave = true;
     else if (!strcmp(argv[i], "--random-seeds")) randomSeeds = true;
     else if (!strcmp(argv[i], "--strict-missing")) strict = true;
     else { usage(); return 2; }
   }
+  if (spawn > 0) {
+    // N ranks as child processes, forked before this process has touched the GPU (the parent never does); each child goes on
+    // as rank r on device r -- no exec, a forked child that has not initialised HIP simply initialises it for itself
+    const std::string idFile = outdir + "/.moptix_comm_" + std::to_string((long)getpid());
+    remove(idFile.c_str());
+    std::vector<pid_t> kids;
+    bool child = false;
+    for (int r = 0; r < spawn && !child; r++) {
+      pid_t pid = fork();
+      if (pid < 0) { perror("fork"); return 1; }
+      if (pid == 0) { child = true; rank = r; ranks = spawn; device = r; commFile = idFile; }
+      else kids.push_back(pid);
+    }
+    if (!child) {
+      int worst = 0;
+      for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128; if (rc > worst) worst = rc; }
+      remove(idFile.c_str());
+      return worst;
+    }
+  }
   try {
     MinimalOptiX app(device);
+    app.rank = rank; app.nRanks = ranks; app.commIdFile = commFile;
     app.fixedWidth = width; app.fixedHeight = height; app.nSuperSampling = spp;
     app.baseSeed = seed; app.reproducibleSeeds = !randomSeeds; app.skipMissingMeshes = !strict;
     app.baseSceneFolder = scenes; app.outputDir = outdir;
@@ -58,7 +91,7 @@ int main(int argc, char** argv) {
     else if (scene == "coffee_pot_standin") app.sceneId = MinimalOptiX::SCENE_COFFEE_POT_STANDIN;
     else { usage(); return 2; }
     app.renderScene(autosave, prefix);
-    if (!autosave) app.saveCurrentFrame(false, prefix);
+    if (!autosave && rank == 0) app.saveCurrentFrame(false, prefix);
     fprintf(stderr, "render %.3f ms (device), BVH build %.3f ms, %u nodes, depth %u\n", app.lastRenderMs,
             app.lastAccel.buildMs, app.lastAccel.nNodes, app.lastAccel.treeDepth);
   } catch (const std::exception& e) {

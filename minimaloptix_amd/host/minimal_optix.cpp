@@ -1,8 +1,10 @@
 #include "minimal_optix.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <random>
 #include <stdexcept>
 
@@ -75,10 +77,38 @@ void MinimalOptiX::setupScene(const char* sceneName) {
   check(upload(scene, context), "upload scene");
 }
 
+// Communicator of this rank: rank 0 makes the id (ncclGetUniqueId behind moptix_comm_unique_id) and publishes it as a file
+// (written under a temporary name, then renamed); the other ranks wait for the file.  moptix_comm_init is collective.
+void MinimalOptiX::setupCommunicator() {
+  if (commIdFile.empty()) throw std::runtime_error("commIdFile is not set (needed for nRanks > 1)");
+  uint8_t id[MOPTIX_COMM_ID_BYTES];
+  if (rank == 0) {
+    check(moptix_comm_unique_id(id), "comm unique id");
+    const std::string tmp = commIdFile + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { if (f) fclose(f); throw std::runtime_error("cannot write " + tmp); }
+    fclose(f);
+    if (rename(tmp.c_str(), commIdFile.c_str()) != 0) throw std::runtime_error("cannot publish " + commIdFile);
+  } else {
+    bool got = false;
+    for (int tries = 0; tries < 1200 && !got; tries++) {         // two minutes
+      FILE* f = fopen(commIdFile.c_str(), "rb");
+      if (f) { got = fread(id, 1, sizeof(id), f) == sizeof(id); fclose(f); }
+      if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+    if (!got) throw std::runtime_error("no communicator id at " + commIdFile);
+  }
+  check(moptix_comm_init(context, id, rank, nRanks), "comm init");
+}
+
 // MinimalOptiX.cpp:540-560
 void MinimalOptiX::renderScene(bool autoSave, std::string fileNamePrefix) {
+  if (nRanks < 1 || rank < 0 || rank >= nRanks) throw std::runtime_error("bad rank / nRanks");
+  check(moptix_set_partition(context, rank, nRanks), "set partition");
   setupScene();
   check(moptix_validate(context), "validate");                 // :542
+  const bool multi = nRanks > 1 || !commIdFile.empty();
+  if (multi) { setupCommunicator(); autoSave = false; }         // progressive snapshots would need a gather each: one-GPU only
   moptix_get_accel_info(context, &lastAccel);
   if (canvas.size() != (size_t)fixedWidth * fixedHeight * 3) canvas.assign((size_t)fixedWidth * fixedHeight * 3, 0);
   moptix_kernel_time(context, nullptr, nullptr, 1);
@@ -98,7 +128,8 @@ void MinimalOptiX::renderScene(bool autoSave, std::string fileNamePrefix) {
       saveCurrentFrame(false, fileNamePrefix + "_" + std::to_string(done));
     }
   }
-  updateContent((float)nSuperSampling, true);                   // :555
+  if (multi) check(moptix_gather_tiles(context, 0), "gather tiles");      // the frame's one exchange: every rank's tiles to rank 0
+  updateContent((float)nSuperSampling, true);                   // :555 (ranks > 0: clears their accuBuffer; their canvas is partial)
   if (autoSave) saveCurrentFrame(false, fileNamePrefix);        // :556-558
   uint64_t n = 0;
   moptix_kernel_time(context, &lastRenderMs, &n, 0);

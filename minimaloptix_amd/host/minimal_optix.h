@@ -68,6 +68,13 @@ public:
   std::string outputDir = ".";
   bool verbose = true;
 
+  // multi-GPU (new): one process per GPU.  With nRanks > 1 renderScene() renders this rank's tiles of the frame
+  // (moptix_set_partition), brings the context's RCCL communicator up (rank 0 writes the 128-byte id to commIdFile, the
+  // others read it) and gathers the tiles into rank 0's accuBuffer (moptix_gather_tiles); only rank 0 resolves and saves.
+  int rank = 0, nRanks = 1;
+  std::string commIdFile;             // shared path for the communicator id; needed when nRanks > 1 (or to force a one-rank communicator)
+  void setupCommunicator();
+
   // measurement of the last renderScene()
   double lastRenderMs = 0.0;          // device time of the render kernels
   moptix_accel_info lastAccel{};

@@ -384,3 +384,78 @@ def test_short_launches_pick_the_packet_kernel_by_themselves():
         assert ctx.get_option("kernel_variant_used") == 3
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_tile_gather_halves_pack_and_unpack_reassemble_the_frame_on_the_device(gpu_ctx):
+    """moptix_pack_tiles / moptix_unpack_tiles are the device halves of moptix_gather_tiles (RCCL send / recv in between):
+    three ranks' shares rendered one after the other, packed, and unpacked into one accuBuffer give the one-GPU frame
+    bit for bit; the packed layout is the work-item order dist.tile_pixel_indices describes."""
+    import torch
+    from minimaloptix_amd import dist as D
+    w, h, n = 101, 53, 3
+    hs = M.HostScene("file:coffee", w, h)
+    seeds = M.launch_seeds(2)
+    gpu_ctx.set_partition(0, 1); gpu_ctx.load(hs); gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+    whole = gpu_ctx.accum_read()
+    cnt = gpu_ctx.packed_tile_floats(n)
+    packed = [torch.zeros(cnt, dtype=torch.float32, device="cuda") for _ in range(n)]
+    try:
+        for r in range(n):
+            gpu_ctx.set_partition(r, n); gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+            gpu_ctx.pack_tiles(r, n, packed[r].data_ptr())
+            idx = D.tile_pixel_indices(w, h, r, n)
+            a = gpu_ctx.accum_read().reshape(-1, 3)
+            got = packed[r].cpu().numpy().reshape(-1, 3)
+            # valid slots in work-item order = this rank's pixels in tile_pixel_indices order; the rest are zero
+            nz = got[np.any(got != 0, axis=1)]
+            assert np.array_equal(nz, a[idx][np.any(a[idx] != 0, axis=1)])
+        gpu_ctx.accum_clear()
+        for r in range(n):
+            gpu_ctx.unpack_tiles(r, n, packed[r].data_ptr())
+    finally:
+        gpu_ctx.set_partition(0, 1)
+    assert np.array_equal(gpu_ctx.accum_read(), whole)
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_of_one_rank_behind_the_c_abi(gpu_ctx):
+    """moptix_comm_unique_id / moptix_comm_init (ncclGetUniqueId / ncclCommInitRank) on the one GPU of the box, and the two
+    collectives on it: with one rank the frame is already in place, so both leave the accuBuffer as it is; the error paths
+    (no communicator, partition that does not match it) are reported, not ignored."""
+    hs = M.HostScene("spheres", 64, 40)
+    seeds = M.launch_seeds(2)
+    ctx = M.Context(0)
+    try:
+        ctx.load(hs); ctx.accum_clear(); ctx.render(seeds)
+        ref = ctx.accum_read()
+        with pytest.raises(M.MoptixError):
+            ctx.gather_tiles(0)                               # no communicator yet
+        uid = M.Context.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        ctx.comm_init(uid, 0, 1)
+        ctx.gather_tiles(0); ctx.reduce_frame(0)
+        assert np.array_equal(ctx.accum_read(), ref)
+        ctx.set_partition(0, 2)
+        with pytest.raises(M.MoptixError):
+            ctx.gather_tiles(0)                               # partition (0, 2) against a communicator of one rank
+        ctx.set_partition(0, 1)
+        ctx.comm_destroy()
+        with pytest.raises(M.MoptixError):
+            ctx.reduce_frame(0)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_cli_multi_rank_path_on_one_gpu(tmp_path):
+    """moptix_render --spawn 1: the parent forks one rank before anything touches the GPU; the rank sets its partition, brings
+    the RCCL communicator up from the id file (class MinimalOptiX::setupCommunicator), renders, gathers (moptix_gather_tiles)
+    and rank 0 writes the frame -- the same bytes as the plain one-GPU run."""
+    exe = os.path.join(REPO, "minimaloptix_amd", "lib", "moptix_render")
+    common = ["--scene", "spheres", "--spp", "3", "--width", "160", "--height", "90", "--outdir", str(tmp_path), "--scenes", M.scenes_dir()]
+    r1 = subprocess.run([exe] + common + ["--out", "one"], capture_output=True, text=True, timeout=300)
+    r2 = subprocess.run([exe] + common + ["--out", "spawned", "--spawn", "1"], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
+    assert np.array_equal(_read_png(os.path.join(str(tmp_path), "one.png")), _read_png(os.path.join(str(tmp_path), "spawned.png")))
+    assert not [f for f in os.listdir(str(tmp_path)) if f.startswith(".moptix_comm_")]
