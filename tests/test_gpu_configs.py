@@ -459,3 +459,39 @@ def test_cli_multi_rank_path_on_one_gpu(tmp_path):
     assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
     assert np.array_equal(_read_png(os.path.join(str(tmp_path), "one.png")), _read_png(os.path.join(str(tmp_path), "spawned.png")))
     assert not [f for f in os.listdir(str(tmp_path)) if f.startswith(".moptix_comm_")]
+
+
+@pytest.mark.gpu
+def test_c2_random_spheres_full_size_properties(gpu_ctx):
+    """BASELINE.json configs[1] at its full size (500 spheres + 33 quads, no acceleration structure, 1280x720, 64 spp; the oracle
+    covers it at reduced size above).  Size-independent properties: the queue kernel's frame equals the per-lane kernel's bit for
+    bit (two independent schedulers over the same per-path code), two half batches accumulate to the whole batch, a two-way tile
+    split reassembles to the same bits, the ray count is that of the counting launch, and every pixel was written."""
+    from minimaloptix_amd import dist as D
+    w, h, spp = 1280, 720, 64
+    hs = M.HostScene("random_spheres", w, h, iarg=497)
+    assert hs.sizes.nSpheres == 500 and hs.sizes.nFaces == 0
+    seeds = M.launch_seeds(spp)
+    gpu_ctx.load(hs)
+    try:
+        gpu_ctx.set_option("analytic_queue", 1)
+        gpu_ctx.accum_clear(); st = gpu_ctx.render_counted(seeds); whole = gpu_ctx.accum_read()
+        assert gpu_ctx.get_option("kernel_variant_used") == 3
+        assert st.samples == w * h * spp and st.primaryRays == st.samples and st.analyticTests == 533 * (st.primaryRays + st.bounceRays)
+        gpu_ctx.accum_clear(); gpu_ctx.render(seeds[:32]); gpu_ctx.render(seeds[32:])
+        assert np.array_equal(gpu_ctx.accum_read(), whole)
+        gpu_ctx.set_option("analytic_queue", 0)
+        gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+        assert gpu_ctx.get_option("kernel_variant_used") == 0
+        assert np.array_equal(gpu_ctx.accum_read(), whole)
+        gpu_ctx.set_option("analytic_queue", -1)
+        parts = np.zeros_like(whole)
+        for r in range(2):
+            gpu_ctx.set_partition(r, 2); gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+            idx = D.tile_pixel_indices(w, h, r, 2)
+            parts.reshape(-1, 3)[idx] = gpu_ctx.accum_read().reshape(-1, 3)[idx]
+        assert np.array_equal(parts, whole)
+    finally:
+        gpu_ctx.set_partition(0, 1); gpu_ctx.set_option("analytic_queue", -1)
+    img = whole / spp
+    assert img.min() >= 0.0 and img.max() <= 1.0 and (img.sum(axis=2) > 0).mean() > 0.99      # bg 0.2: no black pixels

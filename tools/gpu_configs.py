@@ -18,6 +18,14 @@ def timing(kind, kw, res, spp):
     ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); ms, n = ctx.kernel_time()
     print("TIMING %-16s %dx%d spp %d: %.1f ms (%d launches) %.1f Mrays/s rays/sample %.2f  alg %.2f TB/s  analytic tests/s %.3g | tris %d nodes %d depth %d build %.2f ms" % (
         kind, res[0], res[1], spp, ms, n, st.rays / ms / 1e3, st.rays / st.samples, B / ms / 1e9, st.analyticTests / ms * 1e3, a.nTriangles, a.nNodes, a.treeDepth, a.buildMs), flush=True)
+    if a.nTriangles == 0:
+        # scenes without an acceleration structure are FP32-VALU bound -- flops, not bytes.  Per primitive test: sphere
+        # 17 flop (oc 3, b = d.oc 5, c = oc.oc - r^2 7, disc 2; the roots only where disc >= 0 are not counted), quad 20 flop
+        # (plane t 11 incl. the division as one, point 6 -> two projected-edge dots are not reached by most rays, 3 counted)
+        nS, nQ = hs.sizes.nSpheres, hs.sizes.nQuads
+        flops = st.analyticTests * (17.0 * nS + 20.0 * nQ) / max(1, nS + nQ)
+        print("       %-16s FP32: %.3g primitive tests x %.1f flop = %.2f TFLOP/s = %.3f of the 157.3 TFLOP/s vector peak" % (
+            kind, st.analyticTests, (17.0 * nS + 20.0 * nQ) / max(1, nS + nQ), flops / ms / 1e9, flops / ms / 1e9 / 157.3), flush=True)
     return ctx.resolve_rgb8(spp)
 parity("cornell_quads", {}, (256, 256), 4)
 parity("random_spheres", dict(iarg=497), (160, 90), 2)
