@@ -41,7 +41,7 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(DEV_HDRS)
 
 $(LIBDIR)/$(LIBNAME): $(DEV_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(DEV_OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(DEV_OBJS) -ldl -Wl,-rpath,/opt/rocm/lib
 
 build/host_%.o: $(HOST)/%.cpp $(HOST_HDRS)
 	@mkdir -p build

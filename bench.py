@@ -135,6 +135,10 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
         "fabric_GBps": round(fabric_gb / launch_s, 1) if fabric_gb else None,
         "fabric_bytes_per_ray": round(fabric_gb * 1e9 / max(1, rays), 1) if fabric_gb else None,
         "tcc_hit_rate": traffic.get("tcc_hit_rate") if traffic else None,
+        # the unit this kernel's gathers queue at: the CU's vector-memory address path (one L1 tag look-up per clock); PMC
+        "l1_address_unit_busy_frac": traffic.get("ta_busy_frac") if traffic else None,
+        "l1_lookups_per_cu_clock": traffic.get("l1_lookups_per_cu_clock") if traffic else None,
+        "valu_active_frac": traffic.get("valu_active_frac") if traffic else None,
         "reduce_ms_total": round(reduce_ms, 3),
     }
 

@@ -5,6 +5,8 @@
 #include <rccl/rccl.h>
 #include <rocprim/rocprim.hpp>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -266,7 +268,15 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
       a.stackOverflow = c->dOverflow.p;
     }
   }
-  HIPCHK(c, c->dSampleBuf.ensure((size_t)perPass * a.nItems * 3), "alloc per-sample buffer");
+  // the per-sample buffer is the one large allocation (up to "sample_buffer_mb", 16 GB by default; two pipelined contexts
+  // hold one each): when the device cannot give it, run more and smaller passes instead of failing the render
+  for (;;) {
+    const hipError_t e = c->dSampleBuf.ensure((size_t)perPass * a.nItems * 3);
+    if (e == hipSuccess) break;
+    if (e != hipErrorOutOfMemory || perPass <= 1) return hipFail(c, e, "alloc per-sample buffer");
+    (void)hipGetLastError();
+    perPass = (perPass + 1) / 2;
+  }
   a.sampleBuf = c->dSampleBuf.p;
   HIPCHK(c, c->dWork.ensure(2), "alloc work counter");   // [0] work counter, [1] watchdog flag
   a.tileMajor = (useQueue || usePacket) ? c->optTileMajor : 0;
@@ -371,9 +381,37 @@ int tile_deal(moptix_context c, int rank, int nRanks, TileDeal& d) {
   d.width = (int)c->params.width; d.height = (int)c->params.height;
   return MOPTIX_OK;
 }
-int ncclFail(moptix_context c, ncclResult_t r, const char* what) {
-  return fail(c, MOPTIX_ERR_HIP, std::string(what) + ": " + ncclGetErrorString(r));
+// RCCL is bound at the first moptix_comm_* call, not at load time: a host process that already carries an RCCL (PyTorch
+// ships its own librccl.so.1) must keep exactly one copy, and a process that never goes multi-GPU needs none.  dlopen by
+// soname returns the copy that is already loaded, else the one on this library's run path (/opt/rocm/lib).
+struct RcclApi {
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr; decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr; decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclSend) Send = nullptr; decltype(&ncclRecv) Recv = nullptr; decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  bool ok = false; std::string error;
+};
+RcclApi& rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api;
+  tried = true;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { api.error = std::string("cannot load librccl: ") + dlerror(); return api; }
+  bool all = true;
+  auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) { all = false; api.error = std::string("librccl lacks ") + n; } return p; };
+  api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId"); api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+  api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy"); api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+  api.Send = (decltype(api.Send))sym("ncclSend"); api.Recv = (decltype(api.Recv))sym("ncclRecv"); api.Reduce = (decltype(api.Reduce))sym("ncclReduce");
+  api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart"); api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+  api.ok = all;
+  return api;
 }
+int ncclFail(moptix_context c, ncclResult_t r, const char* what) {
+  return fail(c, MOPTIX_ERR_HIP, std::string(what) + ": " + rccl().GetErrorString(r));
+}
+#define RCCL_READY(c) do { if (!rccl().ok) return fail((c), MOPTIX_ERR_STATE, rccl().error); } while (0)
 #define NCCLCHK(c, x, what) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return ncclFail((c), r_, (what)); } while (0)
 
 }  // namespace
@@ -423,7 +461,7 @@ int moptix_destroy(moptix_context c) {
   c->dTileCost.release(); c->dTileCostSorted.release(); c->dTileOrder.release(); c->dTileIota.release(); c->dSortTmp.release();
   c->dAccum.release(); c->dSeeds.release(); c->dWork.release(); c->dCounters.release(); c->dOverflow.release(); c->dRgb8.release();
   c->dTileSend.release(); c->dTileRecv.release();
-  if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+  if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -817,7 +855,8 @@ int moptix_comm_unique_id(uint8_t* id128) {
   if (!id128) return fail(nullptr, MOPTIX_ERR_INVALID, "null id");
   static_assert(sizeof(ncclUniqueId) == MOPTIX_COMM_ID_BYTES, "ncclUniqueId size");
   ncclUniqueId id;
-  ncclResult_t r = ncclGetUniqueId(&id);
+  if (!rccl().ok) return fail(nullptr, MOPTIX_ERR_STATE, rccl().error);
+  ncclResult_t r = rccl().GetUniqueId(&id);
   if (r != ncclSuccess) return ncclFail(nullptr, r, "ncclGetUniqueId");
   memcpy(id128, &id, sizeof(id));
   return MOPTIX_OK;
@@ -825,17 +864,18 @@ int moptix_comm_unique_id(uint8_t* id128) {
 
 int moptix_comm_init(moptix_context c, const uint8_t* id128, int32_t rank, int32_t nRanks) {
   if (!c || !id128 || nRanks < 1 || rank < 0 || rank >= nRanks) return fail(c, MOPTIX_ERR_INVALID, "bad communicator arguments");
+  RCCL_READY(c);
   HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
-  if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+  if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
   ncclUniqueId id; memcpy(&id, id128, sizeof(id));
-  NCCLCHK(c, ncclCommInitRank(&c->comm, nRanks, id, rank), "ncclCommInitRank");
+  NCCLCHK(c, rccl().CommInitRank(&c->comm, nRanks, id, rank), "ncclCommInitRank");
   c->commRank = rank; c->commRanks = nRanks;
   return MOPTIX_OK;
 }
 
 int moptix_comm_destroy(moptix_context c) {
   if (!c) return MOPTIX_ERR_INVALID;
-  if (c->comm) { HIPCHK(c, hipSetDevice(c->device), "hipSetDevice"); (void)hipStreamSynchronize(c->stream); NCCLCHK(c, ncclCommDestroy(c->comm), "ncclCommDestroy"); c->comm = nullptr; }
+  if (c->comm) { HIPCHK(c, hipSetDevice(c->device), "hipSetDevice"); (void)hipStreamSynchronize(c->stream); NCCLCHK(c, rccl().CommDestroy(c->comm), "ncclCommDestroy"); c->comm = nullptr; }
   c->commRank = 0; c->commRanks = 1;
   return MOPTIX_OK;
 }
@@ -891,13 +931,13 @@ int moptix_gather_tiles(moptix_context c, int32_t dstRank) {
     HIPCHK(c, c->dTileSend.ensure(cnt), "alloc tile staging");
     k_pack_tiles<<<grid, block, 0, c->stream>>>(accum_ptr(c), c->dTileSend.p, d);
     HIPCHK(c, hipGetLastError(), "pack tiles");
-    NCCLCHK(c, ncclSend(c->dTileSend.p, cnt, ncclFloat, dstRank, c->comm, c->stream), "ncclSend");
+    NCCLCHK(c, rccl().Send(c->dTileSend.p, cnt, ncclFloat, dstRank, c->comm, c->stream), "ncclSend");
   } else {
     HIPCHK(c, c->dTileRecv.ensure(cnt * (size_t)n), "alloc tile staging");
-    NCCLCHK(c, ncclGroupStart(), "ncclGroupStart");
+    NCCLCHK(c, rccl().GroupStart(), "ncclGroupStart");
     for (int r = 0; r < n; r++)
-      if (r != dstRank) NCCLCHK(c, ncclRecv(c->dTileRecv.p + cnt * (size_t)r, cnt, ncclFloat, r, c->comm, c->stream), "ncclRecv");
-    NCCLCHK(c, ncclGroupEnd(), "ncclGroupEnd");
+      if (r != dstRank) NCCLCHK(c, rccl().Recv(c->dTileRecv.p + cnt * (size_t)r, cnt, ncclFloat, r, c->comm, c->stream), "ncclRecv");
+    NCCLCHK(c, rccl().GroupEnd(), "ncclGroupEnd");
     for (int r = 0; r < n; r++) {                            // the other ranks' tiles into this rank's accuBuffer
       if (r == dstRank) continue;
       TileDeal dr = d; dr.rank = r;
@@ -918,7 +958,7 @@ int moptix_reduce_frame(moptix_context c, int32_t dstRank) {
   HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
   if ((rc = ensure_accum(c)) != MOPTIX_OK) return rc;
   if (c->commRanks > 1)
-    NCCLCHK(c, ncclReduce(accum_ptr(c), accum_ptr(c), 3 * c->accumPixels, ncclFloat, ncclSum, dstRank, c->comm, c->stream), "ncclReduce");
+    NCCLCHK(c, rccl().Reduce(accum_ptr(c), accum_ptr(c), 3 * c->accumPixels, ncclFloat, ncclSum, dstRank, c->comm, c->stream), "ncclReduce");
   HIPCHK(c, hipStreamSynchronize(c->stream), "sync after reduce");
   return MOPTIX_OK;
 }

@@ -126,16 +126,33 @@ PT_HD_BRDF float disney_pdf(const DevMaterial& m, v3 N, v3 L, v3 H) {
 }
 
 // disney.h:48-91
-// Cdlin/Cspec0/Csheen: the material's constants, or the per-hit ones of a textured material
+// What disneyEval derives from the hit alone (N, V and the material), the same for every direction L it is evaluated for at
+// that hit: the tangent frame X, Y (disney.h:76-77), schlickFresnel(NdotV) (:65) and the V factors of the two Smith terms
+// (:81-82, :86).  The reference recomputes them in every call; a Disney hit with three facing lights calls disneyEval four
+// times, so the packet visit (pt_packet.h) takes them once -- the same operations on the same inputs, the same bits.
+struct DisneyView { v3 X, Y; float NdotV, FV, GsV, GrV; };
 template <bool FAST = false>
-PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 Cdlin, v3 Cspec0, v3 Csheen, const Onb& onb, v3 L, v3 V, v3 H) {
+PT_HD_BRDF DisneyView disney_view(const DevMaterial& m, const Onb& onb, v3 V) {
   typedef ShadeMath<FAST> SM;
   const v3 N = onb.normal;
-  float NdotL = dot(N, L), NdotV = dot(N, V), NdotH = dot(N, H), LdotH = dot(L, H);
+  DisneyView dv;
+  dv.NdotV = dot(N, V);
+  dv.FV = schlickFresnel(dv.NdotV);
+  dv.X = SM::normalize(onb.tangent);
+  dv.Y = SM::normalize(cross(N, dv.X));
+  dv.GsV = smithGGgxAniso<FAST>(dv.NdotV, dot(V, dv.X), dot(V, dv.Y), m.ax, m.ay);
+  dv.GrV = smithGGgx<FAST>(dv.NdotV, 0.25f);
+  return dv;
+}
+// Cdlin/Cspec0/Csheen: the material's constants, or the per-hit ones of a textured material
+template <bool FAST = false>
+PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 Cdlin, v3 Cspec0, v3 Csheen, v3 N, const DisneyView& dv, v3 L, v3 H) {
+  typedef ShadeMath<FAST> SM;
+  float NdotL = dot(N, L), NdotV = dv.NdotV, NdotH = dot(N, H), LdotH = dot(L, H);
   const v3 one = mk3(1.f, 1.f, 1.f);
 
   float FL = schlickFresnel(NdotL);
-  float FV = schlickFresnel(NdotV);
+  float FV = dv.FV;
   float Fd90 = 0.5f + 2.f * LdotH * LdotH * m.roughness;
   float Fd = lerp(1.f, Fd90, FL) * lerp(1.f, Fd90, FV);
 
@@ -143,21 +160,25 @@ PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 Cdlin, v3 Cspec0, v3 Csheen, 
   float Fss = lerp(1.0f, Fss90, FL) * lerp(1.0f, Fss90, FV);
   float ss = 1.25f * (Fss * (SM::rcp(NdotL + NdotV) - 0.5f) + 0.5f);
 
-  v3 X = SM::normalize(onb.tangent);
-  v3 Y = SM::normalize(cross(N, X));
+  const v3 X = dv.X, Y = dv.Y;
   float Ds = GTR2Aniso<FAST>(NdotH, dot(H, X), dot(H, Y), m.ax, m.ay);
   float FH = schlickFresnel(LdotH);
   v3 Fs = lerp(Cspec0, one, FH);
-  float Gs = smithGGgxAniso<FAST>(NdotL, dot(L, X), dot(L, Y), m.ax, m.ay) *
-             smithGGgxAniso<FAST>(NdotV, dot(V, X), dot(V, Y), m.ax, m.ay);
+  float Gs = smithGGgxAniso<FAST>(NdotL, dot(L, X), dot(L, Y), m.ax, m.ay) * dv.GsV;
   v3 Fsheen = Csheen * (FH * m.sheen);
   float Dr = GTR1_cc<FAST>(NdotH, m);
   float Fr = lerp(0.04f, 1.f, FH);
-  float Gr = smithGGgx<FAST>(NdotL, 0.25f) * smithGGgx<FAST>(NdotV, 0.25f);
+  float Gr = smithGGgx<FAST>(NdotL, 0.25f) * dv.GrV;
   v3 diffuse = (Cdlin * ((1.0f / kPi) * lerp(Fd, ss, m.subsurface)) + Fsheen) * m.oneMinusMetallic;
   v3 spec = (Fs * Gs) * Ds;
   float cc = 0.25f * m.clearcoat * Gr * Fr * Dr;
   return (diffuse + spec) + cc;
+}
+// one evaluation, as disney.h writes it
+template <bool FAST = false>
+PT_HD_BRDF v3 disney_eval(const DevMaterial& m, v3 Cdlin, v3 Cspec0, v3 Csheen, const Onb& onb, v3 L, v3 V, v3 H) {
+  const DisneyView dv = disney_view<FAST>(m, onb, V);
+  return disney_eval<FAST>(m, Cdlin, Cspec0, Csheen, onb.normal, dv, L, H);
 }
 
 }  // namespace pt

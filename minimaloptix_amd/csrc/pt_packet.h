@@ -54,9 +54,10 @@ struct PacketSink {
 // Material.cu:172-221 for one hit, without the traces (ps.N, ps.V, ps.mat, ps.o set by on_result; ps.light == 0).
 template <bool CNT, bool FAST = false, class Sink = PacketSink>
 PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Counters& ct, const Sink& sink) {
-  const DevMaterial m = load_uniform(sc.mats + ps.mat);
+  const DevMaterial m = load_const(sc.mats + ps.mat);
   packet_clear(pk);
   const Onb onb = make_onb(ps.N);
+  const DisneyView dv = disney_view<FAST>(m, onb, ps.V);      // shared by the evaluations of this hit (up to three lights + the bounce)
   v3 Cdlin = m.Cdlin, Cspec0 = m.Cspec0, Csheen = m.Csheen;
   if (m.albedoTex != 0) {
     Cdlin = ps.cdlin;
@@ -82,7 +83,7 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
       const v3 H = normalize(L + ps.V);
       const float lightPdf = lightDst * lightDst / lt->area / dot(normalOnLight, -L);
       const float pdf = disney_pdf<FAST>(m, ps.N, L, H);
-      const v3 brdf = disney_eval<FAST>(m, Cdlin, Cspec0, Csheen, onb, L, ps.V, H);
+      const v3 brdf = disney_eval<FAST>(m, Cdlin, Cspec0, Csheen, ps.N, dv, L, H);
       v3 w = mk3(0.f, 0.f, 0.f); float inv = 0.f;
       if (lightPdf > 0 && pdf > 0) {
         w = (brdf * powerHeuristic(lightPdf, pdf)) * lt->emission;
@@ -97,7 +98,7 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
   disney_sample(ps.seed, m, onb, ps.V, L, H);
   if (dot(ps.N, L) > 0.0f && dot(ps.N, ps.V) > 0.0f) {
     const float pdf = disney_pdf<FAST>(m, ps.N, L, H);
-    const v3 brdf = disney_eval<FAST>(m, Cdlin, Cspec0, Csheen, onb, L, ps.V, H);
+    const v3 brdf = disney_eval<FAST>(m, Cdlin, Cspec0, Csheen, ps.N, dv, L, H);
     const uint32_t childSeed = fork_seed(ps.seed, ps.depth + 1);
     if (pdf > 0) {
       pk.bscale = brdf; pk.binv = 1.0f / pdf; pk.hasScale = 1; pk.hasBounce = 1;

@@ -60,7 +60,7 @@ struct PathState {
 
 // disneyAnyHit (Material.cu:225-232). Returns true when the ray is terminated.
 PT_HD bool shadow_any_hit(const SceneView& sc, int mat, v3& att) {
-  const DevMaterial m = load_uniform(sc.mats + mat);
+  const DevMaterial m = load_const(sc.mats + mat);
   if (m.kind != MAT_DISNEY) return false;                 // no any-hit program: does not occlude
   if (m.brdfType == BRDF_GLASS) { att = att * m.color; return false; }
   att = mk3(0.f, 0.f, 0.f);
@@ -239,7 +239,7 @@ PT_HD void node_step_with(const PathState& ps, Trav& tv, Stack& st, Counters& ct
 }
 template <bool CNT, class Stack>
 PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
-  const Node128 npv = load_uniform(sc.nodes + tv.node);
+  const Node128 npv = load_const(sc.nodes + tv.node);
   node_step_with<CNT>(ps, tv, st, ct, npv.lox, npv.loy, npv.loz, npv.hix, npv.hiy, npv.hiz, npv.ref[0], npv.ref[1], npv.ref[2], npv.ref[3]);
 }
 
@@ -283,7 +283,7 @@ __device__ __forceinline__ void trav_node_step_quad(const SceneView& sc, const P
     a[0][r] = mk4(0.f, 0.f, 0.f, 0.f); a[1][r] = mk4(0.f, 0.f, 0.f, 0.f);
     if (o4[r] >= 0) {
       const v4* src = reinterpret_cast<const v4*>(sc.nodes + o4[r]) + p;
-      a[0][r] = load_uniform(src); a[1][r] = load_uniform(src + 4);
+      a[0][r] = load_const(src); a[1][r] = load_const(src + 4);
     }
   }
   const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
@@ -321,12 +321,12 @@ PT_HD void leaf_fetch4(const SceneView& sc, int leafRef, int base, LeafChunk& ch
     // whose rate (one per clock), not the bytes, is what per-lane gathers are bounded by
     ch.p0[j] = mk3(0.f, 0.f, 0.f); ch.e0[j] = mk3(0.f, 0.f, 0.f); ch.e1[j] = mk3(0.f, 0.f, 0.f); ch.mat[j] = 0; ch.prim[j] = 0;
     if (base + j < count) {
-      const Tri48 tpv = load_uniform(sc.tris + (first + base + j));
+      const Tri48 tpv = load_const(sc.tris + (first + base + j));
       ch.p0[j] = tpv.p0; ch.e0[j] = tpv.e0; ch.e1[j] = tpv.e1; ch.mat[j] = tpv.mat; ch.prim[j] = tpv.prim;
     }
 #else
     const int k = base + j < count ? base + j : count - 1;
-    const Tri48 tpv = load_uniform(sc.tris + (first + k));
+    const Tri48 tpv = load_const(sc.tris + (first + k));
     const Tri48* tp = &tpv;
     ch.p0[j] = tp->p0; ch.e0[j] = tp->e0; ch.e1[j] = tp->e1; ch.mat[j] = tp->mat; ch.prim[j] = tp->prim;
 #endif
@@ -451,8 +451,8 @@ PT_HD void hit_attributes(const SceneView& sc, const PathState& ps, const Trav& 
     h.front = ray_at(ps.o, ps.d, t); h.back = h.front;
     h.mat = q->mat;
   } else {
-    const Tri48 tpv = load_uniform(sc.tris + tv.bestTri);
-    const TriShade spv = load_uniform(sc.triShade + tv.bestTri);
+    const Tri48 tpv = load_const(sc.tris + tv.bestTri);
+    const TriShade spv = load_const(sc.triShade + tv.bestTri);
     const Tri48* tp = &tpv;
     const TriShade* sp = &spv;
     // both records are requested before either is used: one memory round trip, not two
@@ -501,7 +501,7 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
   cnt<CNT>(ct.closestHits);
   HitAttr h;
   hit_attributes(sc, ps, tv, h);
-  const DevMaterial m = load_uniform(sc.mats + h.mat);
+  const DevMaterial m = load_const(sc.mats + h.mat);
   if (m.kind == MAT_LIGHT) {                                    // light, Material.cu:238-240
     ps.rad = ps.rad + ps.thr * m.emission;
     end_sample(ps);
@@ -553,12 +553,12 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
 // wave.  Same formulas and the same RNG draw order as the reference's program.
 template <bool CNT, bool FAST = false>
 PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
-  const DevMaterial m = load_uniform(sc.mats + ps.mat);
+  const DevMaterial m = load_const(sc.mats + ps.mat);
   int choice = 0;                       // 0 nothing, 1 shadow ray towards a light, 2 BRDF bounce
   v3 L = mk3(0.f, 0.f, 1.f), H = mk3(0.f, 0.f, 1.f), emission = mk3(0.f, 0.f, 0.f);
   float lightDst = 0.f, lightPdf = 0.f;
   while (ps.light < sc.nLights) {
-    const DevLight ltv = load_uniform(sc.lights + ps.light);
+    const DevLight ltv = load_const(sc.lights + ps.light);      // per-lane light index on this path (variant 3)
     const DevLight* lt = &ltv;
     cnt<CNT>(ct.lightLoads);
     v3 pointOnLight, normalOnLight;

@@ -14,12 +14,19 @@ namespace pt {
 
 // child reference encoding: ref >= 0 -> internal node index; ref < 0 -> leaf, ~ref = (firstTri << 3) | (count-1)
 constexpr int kMaxLeaf = 8;
-// Read-only scene tables that a wave indexes uniformly (spheres, quads, lights).  A persistent kernel that also writes
-// global memory gets a VECTOR load for `table[i]` even when i is uniform (the compiler cannot prove that nothing clobbers
-// the table): 64 lanes fetch the same 16 bytes into 64 x 4 registers.  Reading through the constant address space says
-// the table is not written while the kernel runs, and the load becomes one s_load into scalar registers.
+// Scene tables (everything SceneView points at) are IMMUTABLE while a render kernel runs: they are written by uploads and by the
+// acceleration build, never by a trace kernel.  load_const reads them through the constant address space, which is how that
+// contract reaches the compiler.  A persistent kernel stores to global memory all the time (slot records, samples), so without
+// it every scene load counts as clobbered: `table[i]` with a wave-uniform i becomes a VECTOR load per lane (64 lanes fetching
+// the same bytes into 64 x n registers) and per-lane gathers are re-issued after every store.  With it
+//   * a wave-uniform index (light and quad lists, the sphere chunks) becomes one s_load into scalar registers -- load_uniform,
+//   * a per-lane index (nodes, triangle and shading records, the hit's material) stays a vector gather that the compiler may
+//     merge, hoist and keep across the kernel's own stores -- load_const.
+// Both are the same function; the two names say which of the two the call site relies on.  CONSEQUENCE: a kernel that ever
+// updates one of these tables in place (a refit, a writable material) must not read that table through here in the same
+// launch -- it would see hoisted / stale values without any diagnostic.
 template <class T>
-PT_HD T load_uniform(const T* p) {
+PT_HD T load_const(const T* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(sizeof(T) % 4 == 0, "whole dwords");
   typedef __attribute__((address_space(4))) const unsigned int cu32;
@@ -33,6 +40,7 @@ PT_HD T load_uniform(const T* p) {
   return *p;
 #endif
 }
+template <class T> PT_HD T load_uniform(const T* p) { return load_const(p); }      // the index is the same in every lane of the wave
 
 PT_HD int make_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
 PT_HD int leaf_first(int ref) { return (~ref) >> 3; }
@@ -123,7 +131,8 @@ static_assert(sizeof(DevMaterial) == 160, "DevMaterial layout");
 
 struct Cam { v3 origin, horizontal, vertical, scrLowerLeftCorner, u, v; float lensRadius; };
 
-// Everything a launch needs, passed by value as the kernel argument (scalar registers).
+// Everything a launch needs, passed by value as the kernel argument (scalar registers).  Every array behind these pointers is
+// read-only for the duration of a launch (see load_const above).
 struct SceneView {
   int width, height;
   int maxDepth; float minIntensity; float epsT;

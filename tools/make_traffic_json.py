@@ -43,6 +43,13 @@ out = {
     "TCC_HIT_per_launch": per.get("TCC_HIT_sum"), "TCC_MISS_per_launch": per.get("TCC_MISS_sum"),
     "tcc_hit_rate": round(per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in per else None,
     "SQ": {k: per[k] for k in sorted(per) if k.startswith("SQ_")},
+    # vector-memory front end: the CU's address unit (TA) and L1 tag look-ups; GRBM_GUI_ACTIVE is the sum of the 8 XCDs' busy cycles
+    "TA_TA_BUSY_sum": per.get("TA_TA_BUSY_sum"), "TCP_TOTAL_CACHE_ACCESSES_sum": per.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
+    "GRBM_GUI_ACTIVE": per.get("GRBM_GUI_ACTIVE"),
+    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; a SIMD has one vector pipe: share of SIMD-cycles with a VALU instruction in it
+    "valu_active_frac": round(per["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * per["GRBM_GUI_ACTIVE"] / 8.0), 4) if per.get("SQ_ACTIVE_INST_VALU") and per.get("GRBM_GUI_ACTIVE") else None,
+    "ta_busy_frac": round(per["TA_TA_BUSY_sum"] / 256.0 / (per["GRBM_GUI_ACTIVE"] / 8.0), 4) if per.get("TA_TA_BUSY_sum") and per.get("GRBM_GUI_ACTIVE") else None,
+    "l1_lookups_per_cu_clock": round(per["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / (per["GRBM_GUI_ACTIVE"] / 8.0), 4) if per.get("TCP_TOTAL_CACHE_ACCESSES_sum") and per.get("GRBM_GUI_ACTIVE") else None,
     "note": "raw counters x 1024 B; uncalibrated for 16 B/lane gathers (guide: HBM section), compare between builds of this kernel",
 }
 json.dump(out, open(dst, "w"), indent=1)

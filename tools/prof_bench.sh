@@ -12,6 +12,7 @@ run kt "--steps 3 --warmup 1 --no-cpu-baseline" --kernel-trace --stats
 run fetch "--steps 1 --warmup 0 --no-cpu-baseline --no-fast-leg" --kernel-trace --pmc FETCH_SIZE
 run write "--steps 1 --warmup 0 --no-cpu-baseline --no-fast-leg" --kernel-trace --pmc WRITE_SIZE
 run l2 "--steps 1 --warmup 0 --no-cpu-baseline --no-fast-leg" --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+run ta "--steps 1 --warmup 0 --no-cpu-baseline --no-fast-leg" --kernel-trace --pmc TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE
 run sq "--steps 1 --warmup 0 --no-cpu-baseline --no-fast-leg" --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 for f in $OUT/*.log; do echo "== $f"; grep -h '"metric"' $f | cut -c1-400; done
 for f in $(find $OUT/kt -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
