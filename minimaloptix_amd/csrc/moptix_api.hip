@@ -150,8 +150,8 @@ int check_ready(moptix_context c) {
 }
 
 int read_stats(moptix_context c, moptix_stats* stats) {
-  unsigned long long h[40 + 768];
-  HIPCHK(c, hipMemcpy(h, c->dCounters.p, sizeof(unsigned long long) * (c->dCounters.n >= 808 ? 808 : 40), hipMemcpyDeviceToHost), "read counters");
+  unsigned long long h[40 + 768 + 8];
+  HIPCHK(c, hipMemcpy(h, c->dCounters.p, sizeof(unsigned long long) * (c->dCounters.n >= 816 ? 816 : 40), hipMemcpyDeviceToHost), "read counters");
   stats->samples = h[0]; stats->primaryRays = h[1]; stats->bounceRays = h[2]; stats->shadowRays = h[3];
   stats->nodeFetches = h[4]; stats->triTests = h[5]; stats->closestHits = h[6]; stats->lightLoads = h[7];
   stats->analyticTests = h[8]; stats->traversalSteps = h[9]; stats->activeLaneSteps = h[10];
@@ -178,6 +178,11 @@ int read_stats(moptix_context c, moptix_stats* stats) {
     if (h[39]) fprintf(stderr, "[moptix] node runs %llu: node-ready slots waiting in the wave's ring %.1f, leaf ring %.1f (averages at the start of a run)\n",
                        h[39], (double)h[15] / (double)h[39], (double)h[13] / (double)h[39]);
     if (h[32]) fprintf(stderr, "[moptix] batch iterations executing on_result %llu, on_lights %llu, new item %llu (batches %llu)\n", h[33], h[34], h[35], h[11]);
+    if (c->dCounters.n >= 816 && (h[808] | h[809])) {
+      const double rays = (double)(h[1] + h[2] + h[3]);
+      fprintf(stderr, "[moptix] slot-record rows (16 B each) per ray: shading visit loads %.2f stores %.2f | leaf pass loads %.2f stores %.2f | total %.1f B per ray in %.2f shading visits and %.2f leaf visits per ray\n",
+              h[808] / rays, h[809] / rays, h[810] / rays, h[811] / rays, 16.0 * (double)(h[808] + h[809] + h[810] + h[811]) / rays, (double)h[12] / rays, (double)h[23] / rays);
+    }
     if (h[22]) fprintf(stderr, "[moptix] node steps %llu (%.1f lanes avg), leaf passes %llu (%.1f lanes avg)\n", h[9] - h[22],
             (double)(h[10] - h[23]) / (double)(h[9] - h[22]), h[22], (double)h[23] / (double)h[22]);
   }
@@ -303,8 +308,8 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   }
   a.workCounter = c->dWork.p;
   if (counted) {
-    HIPCHK(c, c->dCounters.ensure(40 + 768), "alloc counters");
-    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * (40 + 768), c->stream), "zero counters");
+    HIPCHK(c, c->dCounters.ensure(40 + 768 + 8), "alloc counters");
+    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * (40 + 768 + 8), c->stream), "zero counters");
     HIPCHK(c, hipMemsetAsync(c->dCounters.p + 36, 0xff, sizeof(unsigned long long) * 2, c->stream), "init min counters");
     a.counters = c->dCounters.p;
   }

@@ -333,6 +333,10 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
   }
 
   Counters ct = {};
+  // counting build: 16-byte rows of the slot record moved, by who moves them (DESIGN.md "Slot rows"):
+  // [0] shading visit loads, [1] shading visit stores (incl. the packet's ray / weight rows), [2] leaf pass loads, [3] leaf pass stores
+  uint32_t rows[4] = { 0, 0, 0, 0 };
+#define PT_ROWS(i, n) do { if (CNT) rows[i] += (uint32_t)(n); } while (0)
   uint32_t nodeSteps = 0, nodeLanes = 0, leafPasses = 0, leafLanes = 0, batches = 0, batchLanes = 0, idleSpins = 0;
   unsigned long long tBatch = 0, tSwap = 0, tNode = 0, tLeaf = 0, tStamp = 0;
   const unsigned long long tStart = CNT ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -408,10 +412,10 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       leaf_fetch4(sc, isSwitch ? make_leaf_ref(0, 1) : node0, 0, ch);
       v4 wr = mk4(0.f, 0.f, 1.f, 0.f), wn = mk4(0.f, 0.f, 1.f, 0.f);
       const bool more = fl_more(fl);
-      if (more) wn = slot_load(&cs->ray[cur]);                          // ray cur+1 of the packet sits in ray[cur]: needed if this ray ends here
+      if (more) { wn = slot_load(&cs->ray[cur]); PT_ROWS(2, 1); }       // ray cur+1 of the packet sits in ray[cur]: needed if this ray ends here
       if (!isSwitch) {
-        if (shadow) { if (fl_stat(fl, cur) == 2) wr = slot_load(&cs->att[cur]); }
-        else if (hitValid) wr = slot_load(&cs->hit);
+        if (shadow) { if (fl_stat(fl, cur) == 2) { wr = slot_load(&cs->att[cur]); PT_ROWS(2, 1); } }
+        else if (hitValid) { wr = slot_load(&cs->hit); PT_ROWS(2, 1); }
       }
       // the packet's next ray: same origin, restart at the root
       auto next_ray = [&](int flags) {
@@ -444,11 +448,11 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           if (tv.att.x != oldAtt.x || tv.att.y != oldAtt.y || tv.att.z != oldAtt.z) {
             const bool zero = tv.att.x == 0.f && tv.att.y == 0.f && tv.att.z == 0.f;      // disneyAnyHit on an opaque surface
             nfl = (nfl & ~(3 << (kStatShift + 2 * cur))) | ((zero ? 1 : 2) << (kStatShift + 2 * cur));
-            if (!zero) slot_store(&cold[slot].att[cur], mk4(tv.att.x, tv.att.y, tv.att.z, 0.f));
+            if (!zero) { slot_store(&cold[slot].att[cur], mk4(tv.att.x, tv.att.y, tv.att.z, 0.f)); PT_ROWS(3, 1); }
           }
         } else if (tv.bestTri != oldTri || tv.bestPrim != oldPrim) {
           // most leaf visits find nothing nearer: the hit row is only written when it changed (beta / gamma change with bestTri)
-          slot_store(&cold[slot].hit, mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma));
+          slot_store(&cold[slot].hit, mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma)); PT_ROWS(3, 1);
           nfl |= kHitValid | kShadeFlag;
         }
         if (tv.node == kTravDone && more) {
@@ -500,16 +504,17 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       v4 wh = mk4(0.f, 0.f, 0.f, 0.f), wb = mk4(1.f, 1.f, 1.f, 1.f);
       v4 wp[kPacketShadows], wa[kPacketShadows];
       if (ctl.w & kCtlHoldsAux) axp = f2i(thrIn.w);
-      if (hitValid) wh = slot_load(&cs->hit);
-      if (fl & kHasScale) wb = slot_load(&cs->bsc);
+      PT_ROWS(0, 3);
+      if (hitValid) { wh = slot_load(&cs->hit); PT_ROWS(0, 1); }
+      if (fl & kHasScale) { wb = slot_load(&cs->bsc); PT_ROWS(0, 1); }
 #pragma unroll
       for (int i = 0; i < kPacketShadows; i++) {
         wp[i] = mk4(0.f, 0.f, 0.f, 0.f); wa[i] = mk4(1.f, 1.f, 1.f, 0.f);
         if (i < nSh) {
-          wp[i] = slot_load(&cs->pend[i]);
+          wp[i] = slot_load(&cs->pend[i]); PT_ROWS(0, 1);
           const int ax = (axp >> (9 * i)) & 511;                 // only used with hadAux
           const int stt = hadAux ? fl_stat(W.stack[ax][0], 0) : fl_stat(fl, i);
-          if (stt == 2) wa[i] = hadAux ? slot_load(&cold[ax].att[0]) : slot_load(&cs->att[i]);
+          if (stt == 2) { wa[i] = hadAux ? slot_load(&cold[ax].att[0]) : slot_load(&cs->att[i]); PT_ROWS(0, 1); }
           else if (stt == 1) wa[i] = mk4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -599,6 +604,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       slot_store(&cw->ctl, ctl);
       slot_store(&cw->thr, mk4(ps.thr.x, ps.thr.y, ps.thr.z, i2f(axpNext)));
       slot_store(&cw->rad, mk4(ps.rad.x, ps.rad.y, ps.rad.z, 0.f));
+      PT_ROWS(1, 3);
       if (ps.mode == M_TRACE) {
         // new packet: the brute-force lists for the continuation (radiance) ray, then the rays in trace order: shadow rays
         // in light order, the continuation last; the first goes to LDS, the others to the ray rows
@@ -610,7 +616,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           tb0 = tv.tbest; bp0 = tv.bestPrim;
         }
         const bool hitNow = bp0 >= 0;
-        if (hitNow) slot_store(&cw->hit, mk4(i2f(-1), i2f(bp0), 0.f, 0.f));
+        if (hitNow) { slot_store(&cw->hit, mk4(i2f(-1), i2f(bp0), 0.f, 0.f)); PT_ROWS(1, 1); }
+        // rows the packet's sink wrote during the visit (SlotSink::shadow): one weight row per shadow ray, one ray row for each after the first
+        PT_ROWS(1, pk.nShadow + ((axp >= 0 || pk.nShadow == 0) ? 0 : pk.nShadow - 1));
         useAux = axp >= 0 && pk.nShadow > 0;               // the shadow rays sit in the borrowed slots (SlotSink)
         const int nOwnSh = useAux ? 0 : pk.nShadow;
         const int nRays = nOwnSh + pk.hasBounce;
@@ -623,8 +631,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           if (pk.nShadow == 1) slot_store(&cw->ray[0], rb);
           else if (pk.nShadow == 2) slot_store(&cw->ray[1], rb);
           else slot_store(&cw->ray[2], rb);
+          PT_ROWS(1, 1);
         }
-        if (pk.hasScale) slot_store(&cw->bsc, mk4(pk.bscale.x, pk.bscale.y, pk.bscale.z, pk.binv));
+        if (pk.hasScale) { slot_store(&cw->bsc, mk4(pk.bscale.x, pk.bscale.y, pk.bscale.z, pk.binv)); PT_ROWS(1, 1); }
         W.stack[slot][0] = (nOwnSh << kNShShift) | ((max(nRays, 1) - 1) << kNRayShift) | (nOwnSh > 0 ? kShadowRay : 0) | (pk.nShadow << kPendShift) |
                            (hitNow ? kHitValid : 0) | ((pk.nShadow > 0 || hitNow) ? kShadeFlag : 0) | (pk.hasScale ? kHasScale : 0) |
                            (useAux ? kHasAux : 0);
@@ -767,6 +776,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     const uint32_t v[9] = { wave_sum(ct.samples), wave_sum(ct.primaryRays), wave_sum(ct.bounceRays), wave_sum(ct.shadowRays),
                             wave_sum(ct.nodeFetches), wave_sum(ct.triTests), wave_sum(ct.closestHits), wave_sum(ct.lightLoads),
                             wave_sum(ct.analyticTests) };
+    const uint32_t rw[4] = { wave_sum(rows[0]), wave_sum(rows[1]), wave_sum(rows[2]), wave_sum(rows[3]) };
     if (lane == 0) {
       for (int i = 0; i < 9; i++) atomicAdd(&c[i], (unsigned long long)v[i]);
       atomicAdd(&c[9], (unsigned long long)nodeSteps + leafPasses);
@@ -782,6 +792,8 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       atomicAdd(&c[24], tLocal); atomicAdd(&c[25], tLock); atomicAdd(&c[26], tTxn); atomicAdd(&c[27], tIdle);
       atomicAdd(&c[39], nodeRuns); atomicAdd(&c[15], ringBacklog); atomicAdd(&c[13], leafBacklog);
       atomicAdd(&c[33], nIterResult); atomicAdd(&c[34], nIterLights); atomicAdd(&c[35], nIterGen);
+      atomicAdd(&c[808], (unsigned long long)rw[0]); atomicAdd(&c[809], (unsigned long long)rw[1]);
+      atomicAdd(&c[810], (unsigned long long)rw[2]); atomicAdd(&c[811], (unsigned long long)rw[3]);
       atomicAdd(&c[28], tBLoad); atomicAdd(&c[29], tBRun); atomicAdd(&c[30], tBStore); atomicAdd(&c[31], nTxn); atomicAdd(&c[32], nIter);
     }
   }
