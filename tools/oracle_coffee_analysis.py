@@ -1,6 +1,6 @@
 """Round-3 analysis of the oracle against the reference's demo/coffee.png.  Test infrastructure: uses oracle/.
 
-  python tools/oracle_coffee_analysis.py [spp]          (about 2 minutes at 512 spp on 8 cores)
+  python tools/oracle_coffee_analysis.py [spp] [--shadows]     (about 2 minutes at 512 spp on 8 cores; --shadows: six more renders)
 
 One oracle render of the 240x135 block frame per hypothesis, compared with tests/golden/coffee_8x.npy in the regions of
 tests/test_oracle_kat.py.  Hypotheses (each a switch of the oracle or a change of the scene description, all off / unchanged
@@ -51,7 +51,7 @@ def region_means(img, gold):
 
 
 def main():
-    spp = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    spp = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 512
     gold = np.load(os.path.join(REPO, "tests", "golden", "coffee_8x.npy")).astype(np.float64)
     seeds = M.launch_seeds(spp)
     hs = M.HostScene("file:coffee", 240, 135)
@@ -76,6 +76,47 @@ def main():
         N = min(spp, 256) * (y1 - y0) * (x1 - x0)
         print("   %-30s above 1: %s  before: %s  after: %s" % (n, np.round(ncl.sum(axis=(0, 1)) / N, 3), np.round(raw.sum(axis=(0, 1)) / N, 3),
                                                                np.round(cl.sum(axis=(0, 1)) / N, 3)))
+    print("== displacement of the PNG against the render: coverage of the edge block by the brighter side, PNG vs oracle (G channel)")
+    def cover(img, row0, row1, col, dark_col, bright_col):
+        v, d, b = img[row0:row1, col, 1].mean(), img[row0:row1, dark_col, 1].mean(), img[row0:row1, bright_col, 1].mean()
+        return (v - d) / (b - d)
+    for what, rows, col, dcol, bcol, sign in (("left light panel, right edge", (30, 70), 10, 12, 8, +1), ("right light panel, left edge", (30, 70), 199, 197, 201, -1),
+                                              ("machine body, left edge", (25, 55), 98, 96, 100, -1)):
+        cg, co = cover(gold, rows[0], rows[1], col, dcol, bcol), cover(base, rows[0], rows[1], col, dcol, bcol)
+        print("   %-32s PNG %.2f oracle %.2f of the block -> the PNG's edge sits %.1f pixels to the left" % (what, cg, co, sign * (co - cg) * 8))
+    vt = [(img[0:12, 118:122, 1].mean(axis=1)) for img in (gold, base)]
+    print("   machine top (column 118:122, rows 0..7) PNG    %s" % np.round(vt[0][:8], 2))
+    print("   machine top (column 118:122, rows 0..7) oracle %s  -> about 3 pixels lower in the PNG" % np.round(vt[1][:8], 2))
+    if "--shadows" in sys.argv:
+        print("== is the floor's gap the machine's shadows, lighter?  least squares of (PNG - oracle) against the three lights' shadow depths (G)")
+        S = []
+        for k in range(3):
+            imgs = []
+            for machine in (0, 1):
+                d = hs.to_dict()
+                if not machine:
+                    keep = np.array([material_class(d["materials"][m]) == "floor" for m in d["faceMat"]])
+                    for key in ("vIdx", "nIdx", "tIdx", "faceMat"):
+                        d[key] = d[key][keep]
+                for i, l in enumerate(d["lights"]):
+                    if i != k:
+                        l["emission"] = [0, 0, 0]
+                nl = len(d["lights"])
+                for i, m in enumerate(d["materials"]):
+                    if m["kind"] == 4 and i - (len(d["materials"]) - nl) != k:
+                        m["emission"] = [0, 0, 0]
+                acc, _ = O.Scene(d).render(seeds[:min(spp, 256)])
+                imgs.append(O.image_from_accum(acc, min(spp, 256)).astype(np.float64)[..., 1])
+            S.append(imgs[0] - imgs[1])
+        res = (gold - base)[..., 1]
+        mask = np.zeros((135, 240), bool); mask[100:135, 12:190] = True; mask[100:130, 90:152] = False
+        A = np.stack([s_[mask] for s_ in S], axis=1); b = res[mask]
+        c, *_ = np.linalg.lstsq(A, b, rcond=None)
+        print("   coefficients per light (left, right, top) %s; residual rms %.4f of the gap's rms %.4f" % (np.round(c, 3), np.sqrt(((A @ c - b) ** 2).mean()), np.sqrt((b ** 2).mean())))
+        for n in ("floor, bottom left", "floor beside the base, left", "floor beside the base, right", "floor, bottom right", "floor, middle left"):
+            y0, y1, x0, x1 = REGIONS[n]
+            print("   %-30s gap %+.4f  fitted %+.4f  shadow depths %s" % (n, res[y0:y1, x0:x1].mean(), sum(ck * s_[y0:y1, x0:x1].mean() for ck, s_ in zip(c, S)),
+                                                                        np.round([s_[y0:y1, x0:x1].mean() for s_ in S], 3)))
     for name in ("order", "specular", "pot", "metal0", "floor001"):
         if name == "order":
             O.set_option("draw_order", 3)
