@@ -2,12 +2,11 @@
 
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <stdexcept>
 
 #include "../csrc/pt_math.h"
-
-static const int kMaxLineLength = 2048;
 
 void initDisneyParams(moptix_disney_params& d) {
   d.color = { 1.0f, 1.0f, 1.0f };
@@ -20,109 +19,123 @@ void initDisneyParams(moptix_disney_params& d) {
 }
 
 namespace {
-inline pt::v3 v(const moptix_float3& f) { return pt::mk3(f.x, f.y, f.z); }
-inline moptix_float3 f(const pt::v3& a) { return { a.x, a.y, a.z }; }
+
+constexpr int kLineBytes = 2048;                 // the reference reads lines with fgets(…, 2048, …)
+
+inline pt::v3 toV(const moptix_float3& f) { return pt::mk3(f.x, f.y, f.z); }
+inline moptix_float3 toF(const pt::v3& a) { return { a.x, a.y, a.z }; }
+
+// The grammar of a block, as data.  The reference (scene.cpp:37-51, 69-75, 98-99) runs EVERY sscanf of a block on EVERY line of
+// it and ignores the results, so a line assigns to whichever keys it happens to match (" specular %f" also looks at a
+// "specularTint" line and takes nothing from it), later lines overwrite earlier ones, and unknown lines are skipped silently.
+// A key here is that sscanf format plus where its conversions land.
+struct ScalarKey { const char* format; float moptix_disney_params::*field; };
+struct VectorKey { const char* format; moptix_float3 moptix_disney_params::*field; };
+const VectorKey kMaterialVectors[] = {
+  { " color %f %f %f", &moptix_disney_params::color },
+  { " emission %f %f %f", &moptix_disney_params::emission },
+};
+const ScalarKey kMaterialScalars[] = {
+  { " metallic %f", &moptix_disney_params::metallic },         { " subsurface %f", &moptix_disney_params::subsurface },
+  { " specular %f", &moptix_disney_params::specular },         { " specularTint %f", &moptix_disney_params::specularTint },
+  { " roughness %f", &moptix_disney_params::roughness },       { " anisotropic %f", &moptix_disney_params::anisotropic },
+  { " sheen %f", &moptix_disney_params::sheen },               { " sheenTint %f", &moptix_disney_params::sheenTint },
+  { " clearcoat %f", &moptix_disney_params::clearcoat },       { " clearcoatGloss %f", &moptix_disney_params::clearcoatGloss },
+};
+struct LightVectorKey { const char* format; int which; };       // 0 position, 1 emission, 2 normal, 3 v1, 4 v2
+const LightVectorKey kLightVectors[] = {
+  { " position %f %f %f", 0 }, { " emission %f %f %f", 1 }, { " normal %f %f %f", 2 }, { " v1 %f %f %f", 3 }, { " v2 %f %f %f", 4 },
+};
+
+// Lines of a "{ … }" block: everything up to (not including) the first line with a closing brace goes to `each`.
+// `line` is the caller's buffer on purpose: after the block it holds the closing line, and the block kinds that follow in
+// the same pass of the outer loop are matched against THAT text (scene.cpp:59, 93, 104 test the stale `line`).
+void forEachBlockLine(FILE* file, char* line, const std::function<void(const char*)>& each) {
+  while (fgets(line, kLineBytes, file) && !strchr(line, '}')) each(line);
 }
 
-// Line-oriented, same matching rules and the same order of checks as scene.cpp:18-123:
-// every sscanf pattern is tried on every line of a block; the block kinds are matched on
-// whatever `line` holds after the previous block was consumed.
+}  // namespace
+
 Scene::Scene(const char* fileName) {
   FILE* file = fopen(fileName, "r");
   if (!file) throw std::runtime_error(std::string("Couldn't open ") + fileName + " for reading.");
 
-  std::map<std::string, moptix_disney_params> materialMap;
-  std::map<std::string, std::string> textureMap;
-  char line[kMaxLineLength];
+  std::map<std::string, moptix_disney_params> materialByName;
+  std::map<std::string, std::string> textureByName;
+  char line[kLineBytes];
 
-  while (fgets(line, kMaxLineLength, file)) {
+  // ---- block readers ---------------------------------------------------------------------------------------------
+  auto readMaterial = [&](char* name) {                                  // scene.cpp:28-57; `name` may be renamed by a " name %s" line
+    moptix_disney_params m;
+    initDisneyParams(m);
+    char texture[kLineBytes] = "";
+    int brdf = m.brdfType;
+    forEachBlockLine(file, line, [&](const char* l) {
+      sscanf(l, " name %s", name);
+      sscanf(l, kMaterialVectors[0].format, &(m.*kMaterialVectors[0].field).x, &(m.*kMaterialVectors[0].field).y, &(m.*kMaterialVectors[0].field).z);
+      sscanf(l, " albedoTex %s", texture);
+      sscanf(l, kMaterialVectors[1].format, &(m.*kMaterialVectors[1].field).x, &(m.*kMaterialVectors[1].field).y, &(m.*kMaterialVectors[1].field).z);
+      for (const ScalarKey& k : kMaterialScalars) sscanf(l, k.format, &(m.*k.field));
+      sscanf(l, " brdf %i", &brdf);
+    });
+    m.brdfType = brdf;
+    m.albedoID = 0;                                                      // assigned when the texture is created (upload)
+    materialByName[name] = m;
+    textureByName[name] = texture;
+  };
+  auto readLight = [&]() {                                               // scene.cpp:59-91
+    moptix_light_params light;
+    memset(&light, 0, sizeof(light));
+    moptix_float3 corner[2] = { { 0, 0, 0 }, { 0, 0, 0 } };
+    char kind[20] = "None";
+    forEachBlockLine(file, line, [&](const char* l) {
+      moptix_float3* target[5] = { &light.position, &light.emission, &light.normal, &corner[0], &corner[1] };
+      for (const LightVectorKey& k : kLightVectors) {
+        if (k.which == 3) sscanf(l, " radius %f", &light.radius);        // the reference's order: position emission normal radius v1 v2 type
+        sscanf(l, k.format, &target[k.which]->x, &target[k.which]->y, &target[k.which]->z);
+      }
+      sscanf(l, " type %19s", kind);
+    });
+    if (!strcmp(kind, "Quad")) {
+      const pt::v3 u = toV(corner[0]) - toV(light.position), w = toV(corner[1]) - toV(light.position);
+      light.shape = MOPTIX_LIGHT_QUAD;
+      light.u = toF(u); light.v = toF(w);
+      light.area = pt::length(pt::cross(u, w));
+      light.normal = toF(pt::normalize(pt::cross(u, w)));
+    } else if (!strcmp(kind, "Sphere")) {
+      light.shape = MOPTIX_LIGHT_SPHERE;
+      light.normal = toF(pt::normalize(toV(light.normal)));
+      light.area = 4.0f * pt::kPi * light.radius * light.radius;
+    } else {
+      light.shape = -1;            // the reference leaves the shape uninitialised and throws "No shape for light." at set-up
+    }
+    lights.push_back(light);
+  };
+  auto readProperties = [&]() {                                          // scene.cpp:93-101; parsed, used by nothing
+    forEachBlockLine(file, line, [&](const char* l) { sscanf(l, " width %i", &width); sscanf(l, " height %i", &height); });
+  };
+  auto readMesh = [&]() {                                                // scene.cpp:103-122
+    forEachBlockLine(file, line, [&](const char* l) {
+      char word[kLineBytes];
+      if (sscanf(l, " file %s", word) == 1) meshNames.push_back(word);
+      if (sscanf(l, " material %s", word) == 1) {
+        // meshNames[i] pairs with materials[i] by position: an unknown material name silently shifts every later mesh
+        const auto found = materialByName.find(word);
+        if (found == materialByName.end()) { printf("Could not find material %s\n", word); return; }
+        materials.push_back(found->second);
+        textures.push_back(textureByName[word]);
+      }
+    });
+  };
+
+  // ---- dispatch: one pass per top-level line, the four kinds tested in this order on whatever `line` holds by then ----
+  while (fgets(line, kLineBytes, file)) {
     if (line[0] == '#') continue;
-
-    char name[kMaxLineLength] = { 0 };
-
-    if (sscanf(line, " material %s", name) == 1) {                      // scene.cpp:28-57
-      moptix_disney_params material;
-      initDisneyParams(material);
-      char texName[kMaxLineLength] = "";
-      int brdf = material.brdfType;
-      while (fgets(line, kMaxLineLength, file)) {
-        if (strchr(line, '}')) break;
-        sscanf(line, " name %s", name);
-        sscanf(line, " color %f %f %f", &material.color.x, &material.color.y, &material.color.z);
-        sscanf(line, " albedoTex %s", texName);
-        sscanf(line, " emission %f %f %f", &material.emission.x, &material.emission.y, &material.emission.z);
-        sscanf(line, " metallic %f", &material.metallic);
-        sscanf(line, " subsurface %f", &material.subsurface);
-        sscanf(line, " specular %f", &material.specular);
-        sscanf(line, " specularTint %f", &material.specularTint);
-        sscanf(line, " roughness %f", &material.roughness);
-        sscanf(line, " anisotropic %f", &material.anisotropic);
-        sscanf(line, " sheen %f", &material.sheen);
-        sscanf(line, " sheenTint %f", &material.sheenTint);
-        sscanf(line, " clearcoat %f", &material.clearcoat);
-        sscanf(line, " clearcoatGloss %f", &material.clearcoatGloss);
-        sscanf(line, " brdf %i", &brdf);
-      }
-      material.brdfType = brdf;
-      material.albedoID = 0;
-      materialMap[name] = material;
-      textureMap[name] = texName;
-    }
-
-    if (strstr(line, "light")) {                                         // scene.cpp:59-91
-      moptix_light_params light;
-      memset(&light, 0, sizeof(light));
-      moptix_float3 v1 = { 0, 0, 0 }, v2 = { 0, 0, 0 };
-      char lightType[20] = "None";
-      while (fgets(line, kMaxLineLength, file)) {
-        if (strchr(line, '}')) break;
-        sscanf(line, " position %f %f %f", &light.position.x, &light.position.y, &light.position.z);
-        sscanf(line, " emission %f %f %f", &light.emission.x, &light.emission.y, &light.emission.z);
-        sscanf(line, " normal %f %f %f", &light.normal.x, &light.normal.y, &light.normal.z);
-        sscanf(line, " radius %f", &light.radius);
-        sscanf(line, " v1 %f %f %f", &v1.x, &v1.y, &v1.z);
-        sscanf(line, " v2 %f %f %f", &v2.x, &v2.y, &v2.z);
-        sscanf(line, " type %19s", lightType);
-      }
-      if (strcmp(lightType, "Quad") == 0) {
-        light.shape = MOPTIX_LIGHT_QUAD;
-        const pt::v3 u = v(v1) - v(light.position), w = v(v2) - v(light.position);
-        light.u = f(u); light.v = f(w);
-        light.area = pt::length(pt::cross(u, w));
-        light.normal = f(pt::normalize(pt::cross(u, w)));
-      } else if (strcmp(lightType, "Sphere") == 0) {
-        light.shape = MOPTIX_LIGHT_SPHERE;
-        light.normal = f(pt::normalize(v(light.normal)));
-        light.area = 4.0f * pt::kPi * light.radius * light.radius;
-      } else {
-        light.shape = -1;   // the reference leaves it uninitialised and later throws "No shape for light."
-      }
-      lights.push_back(light);
-    }
-
-    if (strstr(line, "properties")) {                                    // scene.cpp:93-101
-      while (fgets(line, kMaxLineLength, file)) {
-        if (strchr(line, '}')) break;
-        sscanf(line, " width %i", &width);
-        sscanf(line, " height %i", &height);
-      }
-    }
-
-    if (strstr(line, "mesh")) {                                          // scene.cpp:103-122
-      while (fgets(line, kMaxLineLength, file)) {
-        if (strchr(line, '}')) break;
-        char nm[kMaxLineLength];
-        if (sscanf(line, " file %s", nm) == 1) meshNames.push_back(nm);
-        if (sscanf(line, " material %s", nm) == 1) {
-          if (materialMap.find(nm) != materialMap.end()) {
-            materials.push_back(materialMap[nm]);
-            textures.push_back(textureMap[nm]);
-          } else {
-            printf("Could not find material %s\n", nm);
-          }
-        }
-      }
-    }
+    char name[kLineBytes] = { 0 };
+    if (sscanf(line, " material %s", name) == 1) readMaterial(name);
+    if (strstr(line, "light")) readLight();
+    if (strstr(line, "properties")) readProperties();
+    if (strstr(line, "mesh")) readMesh();
   }
   fclose(file);
 }
