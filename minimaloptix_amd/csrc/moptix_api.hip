@@ -136,6 +136,8 @@ void fill_view(moptix_context c, SceneView& v) {
   v.anyDisneyAnalytic = 0;
   for (size_t i = 0; i < c->spheres.size(); i++) if (c->mats[c->sphereMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
   for (size_t i = 0; i < c->quads.size(); i++) if (c->mats[c->quads[i].mat].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
+  v.shadowNearest = 0;
+  for (const DevMaterial& m : c->mats) if (m.kind == MAT_DISNEY && m.brdfType == BRDF_GLASS) v.shadowNearest = 1;
   v.nTris = c->bvh.nTris; v.rootRef = c->bvh.nTris > 0 ? c->bvh.rootRef : kEmptyRef;
   v.nodes = c->bvh.nodes; v.tris = c->bvh.tris; v.triShade = c->bvh.shade;
   v.triUV = (c->anyUV && c->bvh.nTris > 0) ? c->dFaceUV.p : nullptr;

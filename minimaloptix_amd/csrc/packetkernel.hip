@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         tv.inv = mk3(0.f, 0.f, 0.f); tv.tbest = na.w;      // the leaf step does not use 1/d
         tv.node = node0; tv.sp = fl & kSpMask;
         tv.bestTri = -1; tv.bestPrim = -1; tv.beta = 0.f; tv.gamma = 0.f; tv.att = mk3(1.f, 1.f, 1.f);
-        if (shadow) { if (fl_stat(fl, cur) == 2) tv.att = mk3(wr.x, wr.y, wr.z); }
+        if (shadow) { if (fl_stat(fl, cur) == 2) { tv.att = mk3(wr.x, wr.y, wr.z); if (sc.shadowNearest) tv.bestPrim = f2i(wr.w); } }
         else if (hitValid) { tv.bestTri = f2i(wr.x); tv.bestPrim = f2i(wr.y); tv.beta = wr.z; tv.gamma = wr.w; }
         const int oldTri = tv.bestTri, oldPrim = tv.bestPrim;
         const v3 oldAtt = tv.att;
@@ -445,7 +445,13 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         trav_leaf_step_fetched<CNT>(sc, ps, tv, st, ct, ch);
         int nfl = fl & ~kSpMask;
         if (shadow) {
-          if (tv.att.x != oldAtt.x || tv.att.y != oldAtt.y || tv.att.z != oldAtt.z) {
+          if (sc.shadowNearest) {
+            // the verdict of the nearest any-hit surface so far and that surface's id (equal-t rule) travel in the att row
+            if (tv.bestPrim != oldPrim) {
+              nfl = (nfl & ~(3 << (kStatShift + 2 * cur))) | (2 << (kStatShift + 2 * cur));
+              slot_store(&cold[slot].att[cur], mk4(tv.att.x, tv.att.y, tv.att.z, i2f(tv.bestPrim))); PT_ROWS(3, 1);
+            }
+          } else if (tv.att.x != oldAtt.x || tv.att.y != oldAtt.y || tv.att.z != oldAtt.z) {
             const bool zero = tv.att.x == 0.f && tv.att.y == 0.f && tv.att.z == 0.f;      // disneyAnyHit on an opaque surface
             nfl = (nfl & ~(3 << (kStatShift + 2 * cur))) | ((zero ? 1 : 2) << (kStatShift + 2 * cur));
             if (!zero) { slot_store(&cold[slot].att[cur], mk4(tv.att.x, tv.att.y, tv.att.z, 0.f)); PT_ROWS(3, 1); }

@@ -58,13 +58,32 @@ struct PathState {
 // Traversal
 // ---------------------------------------------------------------------------------------
 
-// disneyAnyHit (Material.cu:225-232). Returns true when the ray is terminated.
+// Shadow rays and disneyAnyHit (Material.cu:225-232), rule D5 of DESIGN.md 2.  In OptiX an any-hit program that neither ignores
+// the intersection nor terminates the ray ACCEPTS it: the ray's interval shrinks to that hit and nothing farther along the ray is
+// looked at any more.  disneyAnyHit terminates on an opaque surface (attenuation 0) and does neither on a GLASS surface
+// (attenuation *= color), so with a front-to-back traversal a shadow ray is decided by the NEAREST surface that has the program:
+// opaque -> (0,0,0); glass -> its colour, and whatever lies behind it -- opaque or not -- never gets to block the ray.  That is
+// the deterministic definition used here (nearest by (t, primitive id)); round 3 found it in the reference's demo/coffee.png,
+// where the floor round the machine is lit through the glass pot.  Primitives without the program (lights,
+// non-Disney materials) are not there for a shadow ray.
+//   * scene without a Disney GLASS material (sc.shadowNearest == 0): "some opaque surface on the segment" is the same answer and
+//     the ray stops at the first one found -- shadow_any_hit, returns true when the ray is terminated;
+//   * otherwise the traversal keeps the nearest candidate like a radiance ray does (tbest shrinks, bestPrim for ties) and
+//     tv.att is the verdict of the nearest one so far -- shadow_candidate.
 PT_HD bool shadow_any_hit(const SceneView& sc, int mat, v3& att) {
   const DevMaterial m = load_const(sc.mats + mat);
   if (m.kind != MAT_DISNEY) return false;                 // no any-hit program: does not occlude
   if (m.brdfType == BRDF_GLASS) { att = att * m.color; return false; }
   att = mk3(0.f, 0.f, 0.f);
   return true;                                            // rtTerminateRay
+}
+PT_HD void shadow_candidate(const SceneView& sc, int mat, float t, int prim, float tmin, float& tbest, int& bestPrim, v3& att) {
+  const DevMaterial m = load_const(sc.mats + mat);
+  if (m.kind != MAT_DISNEY) return;
+  if (potential(t, prim, tmin, tbest, bestPrim)) {
+    tbest = t; bestPrim = prim;
+    att = (m.brdfType == BRDF_GLASS) ? m.color : mk3(0.f, 0.f, 0.f);
+  }
 }
 
 // 1/d for the slab planes.  A direction component below 1e-30 in magnitude is treated as +-1e-30 so that
@@ -133,16 +152,21 @@ PT_HD void trav_begin(const SceneView& sc, const PathState& ps, Trav& tv, Counte
       if (sc.mats[mat].kind != MAT_DISNEY) continue;
       const DevSphere s = load_uniform(sc.spheres + i);
       float t1, t2;
-      if (sphere_roots(s.center, s.radius, ps.o, ps.d, t1, t2) &&
-          ((t1 > ps.tmin && t1 < ps.tmax) || (t2 > ps.tmin && t2 < ps.tmax)))
+      if (!sphere_roots(s.center, s.radius, ps.o, ps.d, t1, t2)) continue;
+      if (sc.shadowNearest) {                                // the roots in the order sphereIntersect reports them
+        shadow_candidate(sc, mat, t1, i, ps.tmin, tv.tbest, tv.bestPrim, tv.att);
+        shadow_candidate(sc, mat, t2, i, ps.tmin, tv.tbest, tv.bestPrim, tv.att);
+      } else if ((t1 > ps.tmin && t1 < ps.tmax) || (t2 > ps.tmin && t2 < ps.tmax))
         terminated = shadow_any_hit(sc, mat, tv.att);
     }
     for (int i = 0; i < sc.nQuads && !terminated; i++) {
       const DevQuad q = load_uniform(sc.quads + i);
       if (sc.mats[q.mat].kind != MAT_DISNEY) continue;
       float t;
-      if (quad_test(q.plane, q.v1, q.v2, q.anchor, ps.o, ps.d, ps.tmin, ps.tmax, t))
-        terminated = shadow_any_hit(sc, q.mat, tv.att);
+      if (quad_test(q.plane, q.v1, q.v2, q.anchor, ps.o, ps.d, ps.tmin, ps.tmax, t)) {
+        if (sc.shadowNearest) shadow_candidate(sc, q.mat, t, sc.nSpheres + i, ps.tmin, tv.tbest, tv.bestPrim, tv.att);
+        else terminated = shadow_any_hit(sc, q.mat, tv.att);
+      }
     }
     cnt<CNT>(ct.analyticTests, (uint32_t)(sc.nSpheres + sc.nQuads));
   }
@@ -338,6 +362,9 @@ PT_HD void trav_leaf_step_fetched(const SceneView& sc, const PathState& ps, Trav
     const int first = leaf_first(tv.node), count = leaf_count(tv.node);
     const int triBase = sc.nSpheres + sc.nQuads;
     bool terminated = false;
+    // a shadow ray that keeps its nearest candidate is range-tested by potential() against tbest (callers that resume a ray
+    // hand tbest over as ps.tmax, and a candidate at exactly tbest must still reach the equal-t rule)
+    const float tmaxTest = (ps.kind == RK_SHADOW && sc.shadowNearest) ? kRtDefaultMax : ps.tmax;
     for (int base = 0; base < count && !terminated; base += 4) {
       if (base > 0) leaf_fetch4(sc, tv.node, base, ch);
 #pragma unroll
@@ -345,11 +372,13 @@ PT_HD void trav_leaf_step_fetched(const SceneView& sc, const PathState& ps, Trav
         if (base + j < count && !terminated) {
           cnt<CNT>(ct.triTests);
           v3 n; float t, be, ga;
-          if (tri_test(ps.o, ps.d, ps.tmin, ps.tmax, ch.p0[j], ch.e0[j], ch.e1[j], n, t, be, ga)) {   // meshIntersect, Geometry.cu:121-160
+          if (tri_test(ps.o, ps.d, ps.tmin, tmaxTest, ch.p0[j], ch.e0[j], ch.e1[j], n, t, be, ga)) {   // meshIntersect, Geometry.cu:121-160
             if (ps.kind == RK_RADIANCE) {
               if (potential(t, triBase + ch.prim[j], ps.tmin, tv.tbest, tv.bestPrim)) {
                 tv.tbest = t; tv.bestPrim = triBase + ch.prim[j]; tv.bestTri = first + base + j; tv.beta = be; tv.gamma = ga;
               }
+            } else if (sc.shadowNearest) {
+              shadow_candidate(sc, ch.mat[j], t, triBase + ch.prim[j], ps.tmin, tv.tbest, tv.bestPrim, tv.att);
             } else if (shadow_any_hit(sc, ch.mat[j], tv.att)) terminated = true;
           }
         }

@@ -143,6 +143,7 @@ struct SceneView {
   int nLights;  const DevLight* lights;
   int nMaterials; const DevMaterial* mats;
   int anyDisneyAnalytic;          // any sphere/quad carries a Disney material (shadow any-hit applies)
+  int shadowNearest;              // the scene has a Disney GLASS material: shadow rays are decided by their NEAREST any-hit surface (pt_path.h)
   int nTris; int rootRef;         // rootRef: node index, leaf ref or kEmptyRef
   const Node128* nodes; const Tri48* tris; const TriShade* triShade;
   const TriUV* triUV;             // per face in upload order, or nullptr (no mesh has texcoords)

@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       tv.node = f2i(nb.w); tv.sp = fl & ~kSlotFlags;
       tv.bestTri = -1; tv.bestPrim = -1; tv.beta = 0.f; tv.gamma = 0.f; tv.att = mk3(1.f, 1.f, 1.f);
       if (hitValid) {
-        if (shadow) tv.att = mk3(wh.x, wh.y, wh.z);
+        if (shadow) { tv.att = mk3(wh.x, wh.y, wh.z); if (sc.shadowNearest) tv.bestPrim = f2i(wh.w); }     // verdict + id of the nearest any-hit surface so far
         else { tv.bestTri = f2i(wh.x); tv.bestPrim = f2i(wh.y); tv.beta = wh.z; tv.gamma = wh.w; }
       }
       const int oldTri = tv.bestTri, oldPrim = tv.bestPrim;
@@ -317,11 +317,11 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       SlotStack st = make_stack(slot);
       trav_leaf_step_fetched<CNT>(sc, ps, tv, st, ct, ch);
       // most leaf visits find nothing nearer: the hit row is only written when it changed (beta / gamma change with bestTri)
-      const bool changed = shadow ? (tv.att.x != oldAtt.x || tv.att.y != oldAtt.y || tv.att.z != oldAtt.z)
+      const bool changed = shadow ? ((tv.att.x != oldAtt.x || tv.att.y != oldAtt.y || tv.att.z != oldAtt.z) || (sc.shadowNearest && tv.bestPrim != oldPrim))
                                   : (tv.bestTri != oldTri || tv.bestPrim != oldPrim);
       if (changed) {
         v4 o2;
-        if (shadow) o2 = mk4(tv.att.x, tv.att.y, tv.att.z, 0.f);
+        if (shadow) o2 = mk4(tv.att.x, tv.att.y, tv.att.z, i2f(tv.bestPrim));
         else o2 = mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma);
         slot_store(&cold[slot].hit, o2);
       }
@@ -440,9 +440,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
         nb.x = ps.d.x; nb.y = ps.d.y; nb.z = ps.d.z; nb.w = i2f(tv.node);
         W.nodeA[slot] = na; W.nodeB[slot] = nb;
         const bool shadow = ps.kind == RK_SHADOW;
-        const bool hitNow = shadow ? (tv.att.x != 1.f || tv.att.y != 1.f || tv.att.z != 1.f) : (tv.bestPrim >= 0);
+        const bool hitNow = shadow ? ((tv.att.x != 1.f || tv.att.y != 1.f || tv.att.z != 1.f) || (sc.shadowNearest && tv.bestPrim >= 0)) : (tv.bestPrim >= 0);
         W.stack[slot][0] = ((shadow || tv.bestPrim >= 0) ? kShadeFlag : 0) | (shadow ? kShadowRay : 0) | (hitNow ? kHitValid : 0);
-        if (hitNow) slot_store(&cw->hit, shadow ? mk4(tv.att.x, tv.att.y, tv.att.z, 0.f) : mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma));
+        if (hitNow) slot_store(&cw->hit, shadow ? mk4(tv.att.x, tv.att.y, tv.att.z, i2f(tv.bestPrim)) : mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma));
         if (shadow) {
           slot_store(&cw->pend, mk4(ps.pendW.x, ps.pendW.y, ps.pendW.z, ps.pendInv));
           if (!shadowIn) {      // first light of this Disney hit: N, V, material (and the texture colour) are new

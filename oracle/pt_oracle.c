@@ -134,6 +134,14 @@ static int g_indirect_scale_pct = 100, g_indirect_depth1_off = 0;
  *                        (SURVEY A2 assumes left to right).  bit 0: the quad light's two draws swapped (Material.cu:180),
  *                        bit 1: cosine_sample_hemisphere's two arguments swapped (disney.h:13), bit 2: the camera's jitter pair (Camera.cu:28) */
 static int g_draw_order = 0;
+/*   noshadow_first/last: materials with an index in [first, last] do not stop shadow rays (which occluder class casts the
+ *                        shadows that differ from the PNG?) */
+static int g_noshadow_first = 1, g_noshadow_last = 0;
+/*   shadow_any_opaque_blocks : rounds 1-2 defined a shadow ray by SURVEY A2's order-independent rule (an opaque Disney surface
+ *                         ANYWHERE on the segment zeroes it, every glass surface crossed multiplies by its colour).  Since round 3
+ *                         the default is what OptiX does with a front-to-back traversal (see shadow_attenuation); this switch
+ *                         brings the old rule back for comparison. */
+static int g_shadow_any_opaque_blocks = 0;
 
 static f3 rand_in_unit_sphere(int32_t* seed) {
   f3 res;
@@ -474,6 +482,9 @@ int orc_set_option(const char* name, int value) {
   if (!strcmp(name, "indirect_scale_pct")) { g_indirect_scale_pct = value; return 0; }
   if (!strcmp(name, "indirect_depth1_off")) { g_indirect_depth1_off = value != 0; return 0; }
   if (!strcmp(name, "draw_order")) { g_draw_order = value; return 0; }
+  if (!strcmp(name, "noshadow_first")) { g_noshadow_first = value; return 0; }
+  if (!strcmp(name, "noshadow_last")) { g_noshadow_last = value; return 0; }
+  if (!strcmp(name, "shadow_any_opaque_blocks")) { g_shadow_any_opaque_blocks = value != 0; return 0; }
   return -1;
 }
 
@@ -753,21 +764,87 @@ int orc_closest_hit_batch(const OrcScene* sc, const float* rays, int n, int32_t*
   return 0;
 }
 
-/* Shadow ray (ray type 1): Material.cu:187-193 + disneyAnyHit :225-232, with the
- * deterministic definition of SURVEY A2: an opaque Disney surface anywhere in
- * (tmin,tmax) zeroes the attenuation; every glass Disney surface crossed
- * multiplies by its (untextured) colour; instances without a shadow any-hit
- * program (lights, lambertian/metal/glass spheres and quads) do not occlude. */
+/* Shadow ray (ray type 1): Material.cu:187-193 + disneyAnyHit :225-232.
+ *
+ * OptiX semantics: rtReportIntersection runs the any-hit program of the instance's material for the ray type; a
+ * program that neither calls rtIgnoreIntersection nor rtTerminateRay ACCEPTS the hit, and the ray's tmax becomes that t --
+ * nothing farther along the ray is reported any more.  disneyAnyHit terminates on an opaque surface (attenuation = 0) and does
+ * neither on a GLASS surface (attenuation *= color).  With a front-to-back traversal the shadow ray is therefore decided by the
+ * NEAREST surface that has the program: opaque -> (0,0,0); glass -> that surface's colour, and whatever lies behind the glass,
+ * opaque or not, never blocks.  (In OptiX proper the order is the BVH's and the outcome can differ from ray to ray -- SURVEY D5;
+ * "nearest by (t, primitive id)" is the deterministic definition.)  Instances without the program (lights, lambertian / metal /
+ * glass spheres and quads) are not there for a shadow ray.
+ *
+ * Rounds 1-2 used SURVEY A2's simpler rule (an opaque surface anywhere on the segment blocks); the two only differ when a Disney
+ * GLASS surface is the first thing on the segment and something opaque follows.  The reference's demo/coffee.png shows which one
+ * the reference does: the floor round the machine is lit THROUGH the glass pot past the lid and the body above it. */
 static inline int shadow_apply(const OrcScene* sc, int32_t mat, f3* att) {
   const OrcMaterial* m = &sc->materials[mat];
   if (m->kind != ORC_DISNEY) return 0;
   if (m->brdfType == ORC_BRDF_GLASS) { *att = mul3(*att, ld3(m->color)); return 0; }
+  if (mat >= g_noshadow_first && mat <= g_noshadow_last) return 0;      /* analysis switch, off by default */
   *att = mk3(0.f, 0.f, 0.f);
   return 1; /* rtTerminateRay */
+}
+/* verdict of one candidate: a primitive whose material has the shadow any-hit program, intersected at t */
+static inline void shadow_candidate(const OrcScene* sc, int32_t mat, float t, int32_t prim, float tmin, float* best, int32_t* bestPrim, f3* att) {
+  const OrcMaterial* m = &sc->materials[mat];
+  if (m->kind != ORC_DISNEY) return;
+  if (potential(t, prim, tmin, *best, *bestPrim)) {
+    *best = t; *bestPrim = prim;
+    *att = (m->brdfType == ORC_BRDF_GLASS) ? ld3(m->color) : mk3(0.f, 0.f, 0.f);
+  }
+}
+/* the nearest (t, primitive id) any-hit surface in (tmin, tmax) decides */
+static f3 shadow_nearest(Ctx* cx, f3 o, f3 d, float tmin, float tmax) {
+  const OrcScene* sc = cx->sc;
+  f3 att = mk3(1.f, 1.f, 1.f);
+  float best = tmax; int32_t bestPrim = -1;
+  for (int32_t i = 0; i < sc->nSpheres; i++) {
+    float t1, t2;
+    if (!sphere_roots(&sc->spheres[i], o, d, &t1, &t2)) continue;
+    shadow_candidate(sc, sc->spheres[i].mat, t1, i, tmin, &best, &bestPrim, &att);
+    shadow_candidate(sc, sc->spheres[i].mat, t2, i, tmin, &best, &bestPrim, &att);
+  }
+  for (int32_t i = 0; i < sc->nQuads; i++) {
+    float t;
+    if (quad_test(&sc->quads[i], o, d, tmin, tmax, &t)) shadow_candidate(sc, sc->quads[i].mat, t, sc->nSpheres + i, tmin, &best, &bestPrim, &att);
+  }
+  const int32_t triBase = sc->nSpheres + sc->nQuads;
+  if (sc->nFaces > 0) {
+    if (sc->bruteForceTris || !cx->bvh) {
+      for (int32_t f = 0; f < sc->nFaces; f++) {
+        f3 n; float t, be, ga;
+        if (tri_test(o, d, tmin, tmax, vert(sc, sc->vIdx[3 * f]), vert(sc, sc->vIdx[3 * f + 1]), vert(sc, sc->vIdx[3 * f + 2]), &n, &t, &be, &ga))
+          shadow_candidate(sc, sc->faceMat[f], t, triBase + f, tmin, &best, &bestPrim, &att);
+      }
+    } else {
+      const TriBVH* bvh = cx->bvh;
+      f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+      int32_t stack[128]; int sp = 0; stack[sp++] = 0;
+      while (sp > 0) {
+        const BNode* nd = &bvh->nodes[stack[--sp]];
+        if (!box_hit(nd, o, inv, tmin, best)) continue;
+        if (nd->left < 0) {
+          for (int32_t k = nd->first; k < nd->first + nd->count; k++) {
+            int32_t f = bvh->order[k];
+            f3 n; float t, be, ga;
+            if (tri_test(o, d, tmin, tmax, vert(sc, sc->vIdx[3 * f]), vert(sc, sc->vIdx[3 * f + 1]), vert(sc, sc->vIdx[3 * f + 2]), &n, &t, &be, &ga))
+              shadow_candidate(sc, sc->faceMat[f], t, triBase + f, tmin, &best, &bestPrim, &att);
+          }
+        } else { stack[sp++] = nd->left; stack[sp++] = nd->right; }
+      }
+    }
+  }
+  return att;
 }
 static f3 shadow_attenuation(Ctx* cx, f3 o, f3 d, float tmin, float tmax) {
   const OrcScene* sc = cx->sc;
   f3 att = mk3(1.f, 1.f, 1.f);
+  int anyGlass = 0;
+  for (int32_t i = 0; i < sc->nMaterials; i++) if (sc->materials[i].kind == ORC_DISNEY && sc->materials[i].brdfType == ORC_BRDF_GLASS) anyGlass = 1;
+  if (anyGlass && !g_shadow_any_opaque_blocks) return shadow_nearest(cx, o, d, tmin, tmax);
+  /* no Disney GLASS material in the scene: "the nearest any-hit surface is opaque" == "some opaque surface is on the segment" */
   for (int32_t i = 0; i < sc->nSpheres; i++) {
     float t1, t2;
     if (sc->materials[sc->spheres[i].mat].kind != ORC_DISNEY) continue;

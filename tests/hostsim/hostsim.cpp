@@ -278,6 +278,8 @@ static void make_scene(const hostsim_scene& s, int leafSize, HostScene& hs) {
   v.nQuads = s.nQuads; v.quads = hs.quads.data();
   v.nLights = s.nLights; v.lights = hs.lights.data();
   v.nMaterials = s.nMaterials; v.mats = hs.mats.data();
+  v.shadowNearest = 0;
+  for (const DevMaterial& m : hs.mats) if (m.kind == MAT_DISNEY && m.brdfType == BRDF_GLASS) v.shadowNearest = 1;
   v.anyDisneyAnalytic = 0;
   for (int i = 0; i < s.nSpheres; i++) if (hs.mats[s.sphereMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
   for (int i = 0; i < s.nQuads; i++) if (hs.mats[s.quadMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;

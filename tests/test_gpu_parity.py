@@ -352,3 +352,27 @@ def test_randomised_option_combinations_match_variant0():
     env = dict(os.environ, CASES="10", SEED="7")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 3, 4])
+@pytest.mark.parametrize("glass_below", [True, False])
+def test_shadow_rays_through_glass_nearest_any_hit_surface_decides(gpu_ctx, tmp_path, variant, glass_below):
+    """Rule D5: a shadow ray is decided by its nearest any-hit surface -- a glass pane accepts it and the opaque
+    pane behind never blocks.  Every kernel against the oracle, bit-level ray counts included, for both orders of the panes."""
+    from common import write_glass_over_opaque_scene
+    hs = M.HostScene("file:cornell", 96, 72, base_folder=write_glass_over_opaque_scene(tmp_path, glass_below))
+    seeds = M.launch_seeds(6)
+    default = gpu_ctx.get_option("kernel_variant")
+    try:
+        gpu_ctx.set_option("kernel_variant", variant)
+        gpu_ctx.load(hs); gpu_ctx.accum_clear()
+        st = gpu_ctx.render_counted(seeds)
+        g = gpu_ctx.accum_read()
+        gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+        assert np.array_equal(gpu_ctx.accum_read(), g)
+    finally:
+        gpu_ctx.set_option("kernel_variant", default)
+    o, ost = oracle_scene(hs).render(seeds)
+    assert rmse(g / 6, o / 6) <= RMSE_TIGHT and st.rays == ost.rays and st.shadowRays == ost.shadowRays
+    assert (g.sum() > 1.5 * 96 * 72 * 6 * 0.5 * 0.0) and g.max() > 0

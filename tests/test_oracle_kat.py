@@ -109,7 +109,8 @@ COFFEE_KNOWN = {          # where the PNG and the restated formulas differ, meas
     # reflection of the side lights in Plastic_Orange (roughness 0.001): the PNG is ~1.22x brighter in G/B (R is saturated)
     "light reflected in the body, left": ((20, 60, 101, 109), (-0.09, -0.02)),
     "light reflected in the body, right": ((20, 60, 131, 139), (-0.09, -0.02)),
-    # floor in front of the machine: the PNG is brighter by 0.018, all channels alike
+    # floor in front of the machine: the PNG is brighter by 0.018, all channels alike -- light that reaches the floor THROUGH the glass
+    # pot, which the checkout does not ship (Mesh010.obj); with a stand-in pot it closes: test_floor_round_the_machine_is_lit_through_the_glass_pot
     "floor, bottom left": ((115, 133, 20, 70), (-0.03, -0.008)),
 }
 
@@ -139,6 +140,36 @@ def test_oracle_coffee_matches_reference_demo_blockwise():
     # the two light panels themselves are saturated in both
     for xs in (slice(0, 4), slice(236, 240)):
         assert gold[20:100, xs].min() > 0.999
+
+
+def test_floor_round_the_machine_is_lit_through_the_glass_pot():
+    """Round 3's answer to the floor regions of COFFEE_KNOWN.  coffee.scene's glass pot (Mesh010.obj) is missing from the checkout;
+    in the reference's image the floor round the machine is up to 0.03 brighter than in a render of the shipped meshes.  With
+    a lathe stand-in for the pot AND OptiX's any-hit semantics (a shadow ray is decided by its nearest any-hit surface: the
+    glass pot accepts the ray and the lid / body behind it never block, DESIGN.md 2 rule D5) the oracle meets the PNG there;
+    with the stand-in but the old rule (an opaque surface anywhere blocks) nothing moves."""
+    gold = np.load(os.path.join(GOLD, "coffee_8x.npy"))
+    seeds = M.launch_seeds(384)
+    regions = {"floor, bottom left": (115, 133, 20, 70), "beside the base, left": (108, 128, 50, 92), "beside the base, right": (108, 128, 150, 190)}
+    shipped = oracle_scene(M.HostScene("file:coffee", 240, 135))
+    potted = oracle_scene(M.HostScene("coffee_pot_standin", 240, 135))
+
+    def gaps(sc):
+        out = {}
+        for n, box in regions.items():
+            y0, y1, x0, x1 = box
+            out[n] = float((_coffee_region(sc, seeds, box) - gold[y0:y1, x0:x1]).mean())
+        return out
+    g_shipped, g_potted = gaps(shipped), gaps(potted)
+    try:
+        O.set_option("shadow_any_opaque_blocks", 1)
+        g_old_rule = gaps(potted)
+    finally:
+        O.set_option("shadow_any_opaque_blocks", 0)
+    for n in regions:
+        assert g_shipped[n] < -0.014, (n, g_shipped)                  # the gap of the shipped scene
+        assert abs(g_potted[n]) < 0.008, (n, g_potted)                # closed (the stand-in is not the real pot's shape: a few 1e-3 remain)
+        assert abs(g_old_rule[n] - g_shipped[n]) < 0.003, (n, g_old_rule)
 
 
 def test_stack_overflow_exception_does_not_explain_the_coffee_gap():
@@ -236,3 +267,33 @@ def test_refract_and_offset_unit_cases():
     assert out[0] == 1.0 and out[2] == -2.0 and np.isclose(out[1], 1e-5 + 1e-4)
     L.orc_offset(O.f3(1.0, 1.0, 1.0), O.f3(1, 0, 0), out)
     assert out[0] == np.float32(1.0).view(np.int32).__add__(8192).astype(np.int32).view(np.float32)
+
+
+@pytest.mark.parametrize("glass_below", [True, False])
+def test_shadow_ray_is_decided_by_its_nearest_any_hit_surface(tmp_path, glass_below):
+    """DESIGN.md 2, rule D5 (round 3): disneyAnyHit's GLASS branch accepts the hit (Material.cu:226-227 neither ignores it nor
+    terminates the ray), which in OptiX ends the shadow ray's interval there.  Floor under a glass pane under an opaque pane
+    under the light: the floor is lit through the glass, tinted by its colour; with the panes swapped it is dark.  The old
+    order-independent rule (switch shadow_any_opaque_blocks) calls both dark.  The CPU build of the kernels' per-lane code
+    (tests/hostsim) takes the same decisions as the oracle."""
+    from common import write_glass_over_opaque_scene, hostsim_render
+    hs = M.HostScene("file:cornell", 64, 48, base_folder=write_glass_over_opaque_scene(tmp_path, glass_below))
+    seeds = M.launch_seeds(8)
+    sc = oracle_scene(hs)
+    img, st = sc.render(seeds)
+    try:
+        O.set_option("shadow_any_opaque_blocks", 1)
+        old, _ = sc.render(seeds)
+    finally:
+        O.set_option("shadow_any_opaque_blocks", 0)
+    gain = (img.astype(np.float64) - old).reshape(-1, 3).sum(axis=0) / len(seeds)       # light the new rule lets through, per channel
+    if glass_below:
+        lit = np.abs(img - old).sum(axis=2) > 0
+        assert lit.mean() > 0.02                                                        # the floor strip of the frame
+        assert gain[0] > 1.0 and gain[0] > 1.2 * gain[1] > 1.2 * 1.2 * gain[2] > 0       # tinted by the pane's colour (0.9, 0.6, 0.3)
+        assert (img - old).min() >= 0.0
+    else:
+        assert np.array_equal(img, old)                                                 # opaque pane first: dark either way
+    h, c = hostsim_render(hs, seeds)
+    assert rmse(h / len(seeds), img / len(seeds)) <= 1e-6
+    assert c["shadowRays"] == st.shadowRays and c["bounceRays"] == st.bounceRays
