@@ -142,6 +142,11 @@ static int g_noshadow_first = 1, g_noshadow_last = 0;
  *                         the default is what OptiX does with a front-to-back traversal (see shadow_attenuation); this switch
  *                         brings the old rule back for comparison. */
 static int g_shadow_any_opaque_blocks = 0;
+/*   cos_short_tenth_ulp : disneyPdf's cosTheta = |N.H| is multiplied by (1 - k/10 * 2^-24).  The reference is built with
+ *                         -use_fast_math: normalize() is v * (1 / sqrt(.)) with rsqrt / division approximations of a few ulp, so N and H
+ *                         are not unit vectors to better than ~1e-7 -- and GTR2's 1 + (a^2 - 1) cos^2 with a^2 = 1e-6 (Plastic_Orange)
+ *                         turns a shortfall of ONE ulp of the cosine into +12 % of t at the lobe's peak.  Models a systematic shortfall. */
+static int g_cos_short_tenth_ulp = 0;
 
 static f3 rand_in_unit_sphere(int32_t* seed) {
   f3 res;
@@ -333,6 +338,7 @@ static float disney_pdf(const OrcMaterial* m, f3 N, f3 L, f3 V, f3 H) {
   float clearcoatAlpha = lerpf(0.1f, 0.001f, m->clearcoatGloss);
   float specularRatio = 1.f - diffuseRatio;
   float cosTheta = fabsf(dot3(N, H));
+  if (g_cos_short_tenth_ulp) cosTheta = (float)((double)cosTheta * (1.0 - 0.1 * (double)g_cos_short_tenth_ulp * 5.9604644775390625e-8));
   float pdfGTR1 = GTR1(cosTheta, clearcoatAlpha) * cosTheta;
   float pdfGTR2 = GTR2(cosTheta, specularAlpha) * cosTheta;
   float ratio = 1.0f / (1.0f + m->clearcoat);
@@ -485,6 +491,7 @@ int orc_set_option(const char* name, int value) {
   if (!strcmp(name, "noshadow_first")) { g_noshadow_first = value; return 0; }
   if (!strcmp(name, "noshadow_last")) { g_noshadow_last = value; return 0; }
   if (!strcmp(name, "shadow_any_opaque_blocks")) { g_shadow_any_opaque_blocks = value != 0; return 0; }
+  if (!strcmp(name, "cos_short_tenth_ulp")) { g_cos_short_tenth_ulp = value; return 0; }
   return -1;
 }
 

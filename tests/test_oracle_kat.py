@@ -224,6 +224,27 @@ def test_specular_0625_closes_the_reflection_bands():
             assert lo < dd[1] < hi and lo < dd[2] < hi, (box, dd)
 
 
+def test_two_ulp_cosine_shortfall_closes_the_reflection_bands_too():
+    """The other candidate for the reflection bands, with a mechanism in the reference's build: -use_fast_math (utils_host.cpp:32)
+    makes normalize() a product with an approximate reciprocal square root, so N and H are unit vectors only to ~1e-7, and
+    disneyPdf's GTR2 forms 1 + (a^2 - 1) cos^2 with a^2 = 1e-6: one ulp of the cosine is 12 % of that sum at the lobe's peak.  A
+    SYSTEMATIC shortfall of two ulps (|N||H| = 1 - 1.2e-7) puts both bands within 0.012 of the PNG and moves nothing else
+    (analysis switch cos_short_tenth_ulp; the product path stays correctly rounded, which is the parity contract)."""
+    gold = np.load(os.path.join(GOLD, "coffee_8x.npy"))
+    sc = oracle_scene(M.HostScene("file:coffee", 240, 135))
+    seeds = M.launch_seeds(256)
+    try:
+        O.set_option("cos_short_tenth_ulp", 20)
+        for box in ((20, 60, 103, 112), (20, 60, 132, 139)):
+            y0, y1, x0, x1 = box
+            dd = (_coffee_region(sc, seeds, box) - gold[y0:y1, x0:x1]).mean(axis=(0, 1))
+            assert -0.02 < dd[1] < 0.01 and -0.02 < dd[2] < 0.01, (box, dd)
+        y0, y1, x0, x1 = 10, 50, 20, 80
+        assert np.abs((_coffee_region(sc, seeds[:128], (y0, y1, x0, x1)) - gold[y0:y1, x0:x1]).mean(axis=(0, 1))).max() < 2e-3
+    finally:
+        O.set_option("cos_short_tenth_ulp", 0)
+
+
 def test_light_reflection_in_roughness_0001_plastic_depends_on_rounding():
     """Plastic_Orange has roughness 0.001: GTR2's 1 + (a^2 - 1) cos^2 with a^2 = 1e-6 is formed from a cosine known to
     6e-8, so the weight of a specular bounce depends on how each binary32 operation before it rounded.  Evaluating

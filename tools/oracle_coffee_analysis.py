@@ -8,7 +8,11 @@ in the restated reference):
   stack     the 9608-byte OptiX stack overflows at recursion depth D and Exception.cu adds white instead of the sample
   order     unspecified C++ evaluation order of the rand() pairs (quad light, cosine_sample_hemisphere, camera jitter)
   specular  DisneyParams.specular 0.625 instead of initDisneyParams' 0.5
-  pot       the lathe stand-in for the missing glass pot
+  cos2ulp   disneyPdf's cosTheta = |N.H| short by two ulps (1.2e-7): what a -use_fast_math normalize() that leaves N and H one ulp
+            short each does to GTR2's 1 + (a^2 - 1) cos^2 at a^2 = 1e-6 (oracle switch cos_short_tenth_ulp = 20)
+  pot       the lathe stand-in for the missing glass pot, shadow rays decided by their nearest any-hit surface (the default since
+            round 3: OptiX's acceptance semantics, DESIGN.md 2 rule D5) -- and pot_oldrule: the same scene under rounds 1-2's rule
+            (an opaque surface anywhere on the segment blocks)
   metal0    the two Metal meshes made black (how much light reaches the floor by way of the chrome parts)
   floor001  Floor roughness 0.001 (sampling alpha = evaluation alpha: no 10x mismatch)
 and the statistics of the per-sample clamp (Camera.cu:39): share of samples above 1 and the mean before the clamp."""
@@ -117,14 +121,18 @@ def main():
             y0, y1, x0, x1 = REGIONS[n]
             print("   %-30s gap %+.4f  fitted %+.4f  shadow depths %s" % (n, res[y0:y1, x0:x1].mean(), sum(ck * s_[y0:y1, x0:x1].mean() for ck, s_ in zip(c, S)),
                                                                         np.round([s_[y0:y1, x0:x1].mean() for s_ in S], 3)))
-    for name in ("order", "specular", "pot", "metal0", "floor001"):
+    for name in ("order", "specular", "cos2ulp", "pot", "pot_oldrule", "metal0", "floor001"):
         if name == "order":
             O.set_option("draw_order", 3)
+        if name == "pot_oldrule":
+            O.set_option("shadow_any_opaque_blocks", 1)
+        if name == "cos2ulp":
+            O.set_option("cos_short_tenth_ulp", 20)
         try:
-            s2 = O.Scene(M.HostScene("coffee_pot_standin", 240, 135).to_dict()) if name == "pot" else sc if name == "order" else variant_scene(hs, name)
+            s2 = O.Scene(M.HostScene("coffee_pot_standin", 240, 135).to_dict()) if name.startswith("pot") else sc if name in ("order", "cos2ulp") else variant_scene(hs, name)
             acc, _ = s2.render(seeds)
         finally:
-            O.set_option("draw_order", 0)
+            O.set_option("draw_order", 0); O.set_option("shadow_any_opaque_blocks", 0); O.set_option("cos_short_tenth_ulp", 0)
         img = O.image_from_accum(acc, spp).astype(np.float64)
         print("== variant %s: oracle - PNG per region (R G B)" % name)
         for n, d in region_means(img, gold).items():
