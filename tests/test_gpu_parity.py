@@ -375,4 +375,4 @@ def test_shadow_rays_through_glass_nearest_any_hit_surface_decides(gpu_ctx, tmp_
         gpu_ctx.set_option("kernel_variant", default)
     o, ost = oracle_scene(hs).render(seeds)
     assert rmse(g / 6, o / 6) <= RMSE_TIGHT and st.rays == ost.rays and st.shadowRays == ost.shadowRays
-    assert (g.sum() > 1.5 * 96 * 72 * 6 * 0.5 * 0.0) and g.max() > 0
+    assert st.shadowRays > 0 and g.max() > 0
