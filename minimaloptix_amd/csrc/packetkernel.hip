@@ -211,14 +211,18 @@ struct SlotSink {
   }
 };
 
-template <bool CNT, bool SHARED, bool FAST = false>
+// NEAR: the scene has a Disney GLASS material, shadow rays keep their nearest any-hit candidate (pt_path.h, rule D5).  A template
+// parameter so that scenes without one -- the benchmark scene -- run code in which that logic does not exist.
+template <bool CNT, bool SHARED, bool FAST = false, bool NEAR = false>
 __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(const LaunchArgs a) {
   constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
   constexpr int RC = ring_capacity(NS);                  // ring capacity (power of two >= NS)
   __shared__ PoolLds<NS> sPool[SHARED ? 1 : kWaves];
   __shared__ WavePriv<NS> sPriv[kWaves];
 
-  const SceneView& sc = a.scene;
+  SceneView scv = a.scene;
+  scv.shadowNearest = NEAR ? 1 : 0;                 // compile-time constant from here on
+  const SceneView& sc = scv;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   PoolLds<NS>& W = sPool[SHARED ? 0 : wave];
   const int gpool = SHARED ? blockIdx.x : blockIdx.x * kWaves + wave;
@@ -811,15 +815,15 @@ int packetkernel_lds_stack_entries() { return kStackN; }
 size_t packetkernel_cold_bytes(int nBlocks) { return (size_t)nBlocks * kWaves * kP * sizeof(SlotCold); }
 size_t packetkernel_overflow_ints(int nBlocks, int ovfDepth) { return (size_t)nBlocks * kWaves * kP * (size_t)ovfDepth; }
 
+template <bool CNT, bool FAST>
+static void launch_pk(dim3 grid, dim3 block, hipStream_t stream, const LaunchArgs& a) {
+  if (a.scene.shadowNearest) pt_packetkernel<CNT, true, FAST, true><<<grid, block, 0, stream>>>(a);
+  else                       pt_packetkernel<CNT, true, FAST, false><<<grid, block, 0, stream>>>(a);
+}
 hipError_t launch_packetkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading) {
   dim3 grid(nBlocks), block(kBlockThreads);
-  if (fastShading) {
-    if (counted) pt_packetkernel<true, true, true><<<grid, block, 0, stream>>>(a);
-    else         pt_packetkernel<false, true, true><<<grid, block, 0, stream>>>(a);
-  } else {
-    if (counted) pt_packetkernel<true, true, false><<<grid, block, 0, stream>>>(a);
-    else         pt_packetkernel<false, true, false><<<grid, block, 0, stream>>>(a);
-  }
+  if (fastShading) { if (counted) launch_pk<true, true>(grid, block, stream, a); else launch_pk<false, true>(grid, block, stream, a); }
+  else             { if (counted) launch_pk<true, false>(grid, block, stream, a); else launch_pk<false, false>(grid, block, stream, a); }
   return hipGetLastError();
 }
 

@@ -167,14 +167,18 @@ __device__ __forceinline__ int route(int node, int kind, int bestPrim) {
   return node >= 0 ? Q_NODE : Q_LEAF;
 }
 
-template <bool CNT, bool SHARED, bool FAST = false>
+// NEAR: the scene has a Disney GLASS material, shadow rays keep their nearest any-hit candidate (pt_path.h, rule D5).  A template
+// parameter so that scenes without one -- the benchmark scene -- run code in which that logic does not exist.
+template <bool CNT, bool SHARED, bool FAST = false, bool NEAR = false>
 __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(const LaunchArgs a) {
   constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
   constexpr int RC = ring_capacity(NS);                  // ring capacity (power of two >= NS)
   __shared__ PoolLds<NS> sPool[SHARED ? 1 : kWaves];
   __shared__ WavePriv<NS> sPriv[kWaves];
 
-  const SceneView& sc = a.scene;
+  SceneView scv = a.scene;
+  scv.shadowNearest = NEAR ? 1 : 0;                 // compile-time constant from here on
+  const SceneView& sc = scv;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   PoolLds<NS>& W = sPool[SHARED ? 0 : wave];
   const int gpool = SHARED ? blockIdx.x : blockIdx.x * kWaves + wave;
@@ -628,15 +632,16 @@ int queuekernel_slots() { return kP; }
 size_t queuekernel_cold_bytes(int nBlocks) { return (size_t)nBlocks * kWaves * kP * sizeof(SlotCold); }
 size_t queuekernel_overflow_ints(int nBlocks, int ovfDepth) { return (size_t)nBlocks * kWaves * kP * (size_t)ovfDepth; }
 
+template <bool CNT, bool FAST>
+static void launch_qk(dim3 grid, dim3 block, hipStream_t stream, const LaunchArgs& a) {
+  if (a.scene.shadowNearest) pt_queuekernel<CNT, true, FAST, true><<<grid, block, 0, stream>>>(a);
+  else                       pt_queuekernel<CNT, true, FAST, false><<<grid, block, 0, stream>>>(a);
+}
 hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading) {
   dim3 grid(nBlocks), block(kBlockThreads);
-  if (fastShading) {       // opt-in approximate BRDF arithmetic (pt_disney.h ShadeMath); default variant only
-    if (counted) pt_queuekernel<true, true, true><<<grid, block, 0, stream>>>(a);
-    else         pt_queuekernel<false, true, true><<<grid, block, 0, stream>>>(a);
-  } else {
-    if (counted) pt_queuekernel<true, true><<<grid, block, 0, stream>>>(a);
-    else         pt_queuekernel<false, true><<<grid, block, 0, stream>>>(a);
-  }
+  // fastShading: opt-in approximate BRDF arithmetic (pt_disney.h ShadeMath)
+  if (fastShading) { if (counted) launch_qk<true, true>(grid, block, stream, a); else launch_qk<false, true>(grid, block, stream, a); }
+  else             { if (counted) launch_qk<true, false>(grid, block, stream, a); else launch_qk<false, false>(grid, block, stream, a); }
   return hipGetLastError();
 }
 
