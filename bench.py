@@ -132,6 +132,10 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
         "algorithmic_GBps": round(achieved_gbs, 1), "algorithmic_frac_of_hbm": round(achieved_gbs / HBM_PEAK_GBS, 4),
         "hbm_peak_GBps": HBM_PEAK_GBS,
         "hbm_frac": round(fabric_gb / launch_s / HBM_PEAK_GBS, 4) if fabric_gb else None,
+        # FETCH_SIZE tallies 64 B per fabric read request; a request of this kernel's gathers fills a 128-byte line (calibrated with
+        # the gather micro-benchmark, profiles/r03_fetch_size_calibration.txt): upper figure with the read side doubled
+        "hbm_frac_if_128B_reads": round((2.0 * traffic["FETCH_SIZE_KB_per_launch"] + traffic["WRITE_SIZE_KB_per_launch"]) * 1024 / 1e9 / launch_s / HBM_PEAK_GBS, 4)
+        if traffic and traffic.get("FETCH_SIZE_KB_per_launch") else None,
         "fabric_GBps": round(fabric_gb / launch_s, 1) if fabric_gb else None,
         "fabric_bytes_per_ray": round(fabric_gb * 1e9 / max(1, rays), 1) if fabric_gb else None,
         "tcc_hit_rate": traffic.get("tcc_hit_rate") if traffic else None,
