@@ -28,6 +28,8 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+NODE_BYTES = 64             # the node record the kernels fetch (csrc/pt_types.h Node64)
+VALU_ISSUE_PEAK_G = 256 * 4 * 2.4 / 4.0     # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 vector instruction per SIMD every 4 clocks at 2.4 GHz (same guide)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
 GATHER_CEILING_FILE = os.path.join("profiles", "r03_gather_ceiling.txt")    # output of tools/micro/gather on MI355X
 
@@ -47,18 +49,19 @@ def source_hash(repo):
 
 
 def algorithmic_bytes(st, pixels):
-    """B = NODE*N_node + 48*N_tri + 108*N_hit + 72*N_lightLoads + 24*N_accum, with NODE = 128:
-    the node record is a four-child 128-byte node (one L2 line) since the binary tree was widened; N_node counts
-    those fetches.  N_accum is counted per pixel per launch batch (the per-sample buffer traffic is not claimed)."""
-    return 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * pixels
+    """B = 64*N_node + 48*N_tri + 108*N_hit + 72*N_lightLoads + 24*N_accum.  N_node counts fetches of
+    four-child nodes in their 64-byte form (csrc/pt_types.h Node64: what the kernels read since round 3; the 128-byte
+    form of rounds 1-2 is only the builder's output now).  N_accum is counted per pixel per launch batch (the per-sample
+    buffer traffic is not claimed)."""
+    return NODE_BYTES * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * pixels
 
 
 def gather_ceilings(repo):
-    """Ceilings of the traversal's access pattern (every lane fetches its own 128-byte record, next address dependent
-    on the data) measured on MI355X with tools/micro/gather.hip; the committed output is the evidence (profiles/).
-    Returns {"l2_128": best TB/s over all occupancies / chains for 128-B records from the 3.1 MB table (one XCD's L2
-    holds it), "l2_128_at_12_waves": the dependent single-chain rate at the trace kernel's own 12 waves per CU,
-    "ic_128": best from the 38 MB table (Infinity Cache)} in GB/s, or None when the file is missing."""
+    """Ceilings of the traversal's access pattern (every lane fetches its own record, next address dependent on the data)
+    measured on MI355X with tools/micro/gather.hip; the committed output is the evidence (profiles/).  Per record size
+    R in (64, 128): "l2_R" = best GB/s over all occupancies / chains from the 3.1 MB table (one XCD's L2 holds it),
+    "l2_R_at_12_waves" = the dependent single-chain rate at the trace kernel's own 12 waves per CU, "ic_R" = best from the
+    38 MB table (Infinity Cache).  None when the file is missing."""
     try:
         rows = [l.split() for l in open(os.path.join(repo, GATHER_CEILING_FILE)) if l.strip() and not l.startswith("#")]
     except OSError:
@@ -66,13 +69,11 @@ def gather_ceilings(repo):
     best = {}
     for r in rows:
         rec, mb, waves, chains, tbs = int(r[0]), float(r[1]), int(r[2]), int(r[3]), float(r[6])
-        if rec != 128:
-            continue
-        for key, ok in (("l2_128", mb < 4.0), ("l2_128_at_12_waves", mb < 4.0 and waves == 12 and chains == 1),
-                        ("ic_128", 30.0 < mb < 50.0)):
+        for key, ok in (("l2_%d" % rec, mb < 4.0), ("l2_%d_at_12_waves" % rec, mb < 4.0 and waves == 12 and chains == 1),
+                        ("ic_%d" % rec, 30.0 < mb < 50.0)):
             if ok:
                 best[key] = max(best.get(key, 0.0), tbs * 1000.0)
-    return best if "l2_128" in best else None
+    return best if "l2_128" in best and "l2_64" in best else None
 
 
 def cpu_baseline(width, height, target_s):
@@ -112,24 +113,48 @@ def read_traffic(repo):
 
 
 def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per_ray, rays, reduce_ms, kernel, traffic, ceil):
-    """The dominant kernel against the roof that binds it.  The traversal's bytes (SURVEY 8d's algorithmic count) are
-    served by the XCDs' L2s and the Infinity Cache -- the 3.1 MB of nodes and 16 MB of triangle records never leave
-    them -- and every fetch depends on the one before it, so the roof is the chip's rate for dependent per-lane gathers
-    of 128-byte records from an L2-resident table (profiles/r03_gather_ceiling.txt), not HBM.  `frac` is measured
-    against the best rate that micro-benchmark reaches at ANY occupancy; HBM enters as `hbm_frac` (bytes that really
-    crossed the fabric, PMC) and as the SURVEY figure `algorithmic_frac_of_hbm` (can exceed 1: not a physical bound)."""
+    """The dominant kernel against the roof that binds it.
+
+    What binds it: the issue rate of the vector ALUs at the three waves per SIMD the kernel's
+    registers and LDS allow.  Evidence: the counters (vector pipes busy 0.7 of all cycles at 0.57 of the lanes, the L1
+    address unit well below that, fabric a quarter of HBM's peak); halving the node record (7 -> 4 look-ups per node)
+    moved the frame by 1.6 %; the traversal-only build of the kernel steps the same 68 G nodes/s with either record;
+    every instruction added to the node step shows up at 3-4 clocks.  So `achieved` / `peak` / `frac` are wave-level
+    vector instructions per second -- per launch from the committed PMC pass of THIS device code (profiles/traffic.json,
+    SQ_INSTS_VALU), divided by the launch duration measured live -- against one instruction per SIMD per 4 clocks.
+    Without a PMC pass for this device code the block falls back to the memory side below.
+
+    The memory side (SURVEY 8d's algorithmic bytes) stays as named fields: the traversal's bytes are served by the XCDs'
+    L2s and the Infinity Cache, every fetch depends on the one before it, and the chip's rate for such per-lane gathers
+    of 64-byte records from an L2-resident table is profiles/r03_gather_ceiling.txt (`gather_*`); HBM enters as
+    `hbm_frac` (bytes that really crossed the fabric, PMC) and as the SURVEY figure `algorithmic_frac_of_hbm`."""
     launch_s = launch_ms * 1e-3
     fabric_gb = traffic.get("traffic_GB_per_launch") if traffic else None
-    peak = ceil["l2_128"] if ceil else None
-    return {
-        "bound": "l2_gather_latency", "achieved": round(achieved_gbs, 1), "peak": round(peak, 1) if peak else None, "unit": "GB/s",
-        "frac": round(achieved_gbs / peak, 4) if peak else None, "traffic": fabric_gb,
-        "peak_source": GATHER_CEILING_FILE + " (tools/micro/gather.hip: dependent per-lane gathers of 128-B records, 3.1 MB table, best over occupancies)",
-        "peak_at_kernel_occupancy_GBps": round(ceil["l2_128_at_12_waves"], 1) if ceil and "l2_128_at_12_waves" in ceil else None,
-        "infinity_cache_gather_GBps": round(ceil["ic_128"], 1) if ceil and "ic_128" in ceil else None,
+    gpeak = ceil["l2_%d" % NODE_BYTES] if ceil else None
+    valu = (traffic.get("SQ") or {}).get("SQ_INSTS_VALU") if traffic else None
+    lanes = None
+    if traffic and (traffic.get("SQ") or {}).get("SQ_THREAD_CYCLES_VALU") and traffic["SQ"].get("SQ_ACTIVE_INST_VALU"):
+        lanes = round(traffic["SQ"]["SQ_THREAD_CYCLES_VALU"] / (64.0 * traffic["SQ"]["SQ_ACTIVE_INST_VALU"]), 4)
+    if valu:
+        ach = valu / launch_s / 1e9
+        head = {"bound": "valu_issue", "achieved": round(ach, 1), "peak": round(VALU_ISSUE_PEAK_G, 1), "unit": "Ginstr/s",
+                "frac": round(ach / VALU_ISSUE_PEAK_G, 4), "traffic": fabric_gb,
+                "peak_source": "256 CUs x 4 SIMDs x 2.4 GHz / 4 clocks per wave64 vector instruction; achieved = SQ_INSTS_VALU per launch "
+                               "(profiles/traffic.json, PMC pass of this device code) / launch duration measured here"}
+    else:
+        head = {"bound": "l2_gather_latency", "achieved": round(achieved_gbs, 1), "peak": round(gpeak, 1) if gpeak else None, "unit": "GB/s",
+                "frac": round(achieved_gbs / gpeak, 4) if gpeak else None, "traffic": fabric_gb,
+                "peak_source": GATHER_CEILING_FILE + " (no PMC pass for this device code: memory side only)"}
+    head.update({
+        "valu_instructions_per_ray": round(valu / max(1, rays), 2) if valu else None,      # wave-level instructions per ray traced
+        "valu_lane_utilisation": lanes,
         "kernel": kernel, "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
         "algorithmic_bytes_per_launch": int(bytes_per_launch), "bytes_per_ray": round(bytes_per_ray, 1),
         "algorithmic_GBps": round(achieved_gbs, 1), "algorithmic_frac_of_hbm": round(achieved_gbs / HBM_PEAK_GBS, 4),
+        "gather_peak_GBps": round(gpeak, 1) if gpeak else None, "gather_frac": round(achieved_gbs / gpeak, 4) if gpeak else None,
+        "gather_peak_source": GATHER_CEILING_FILE + " (tools/micro/gather.hip: dependent per-lane gathers of %d-B records, 3.1 MB table, best over occupancies)" % NODE_BYTES,
+        "gather_peak_at_kernel_occupancy_GBps": round(ceil["l2_%d_at_12_waves" % NODE_BYTES], 1) if ceil and ("l2_%d_at_12_waves" % NODE_BYTES) in ceil else None,
+        "infinity_cache_gather_GBps": round(ceil["ic_%d" % NODE_BYTES], 1) if ceil and ("ic_%d" % NODE_BYTES) in ceil else None,
         "hbm_peak_GBps": HBM_PEAK_GBS,
         "hbm_frac": round(fabric_gb / launch_s / HBM_PEAK_GBS, 4) if fabric_gb else None,
         # FETCH_SIZE tallies 64 B per fabric read request; a request of this kernel's gathers fills a 128-byte line (calibrated with
@@ -139,12 +164,13 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
         "fabric_GBps": round(fabric_gb / launch_s, 1) if fabric_gb else None,
         "fabric_bytes_per_ray": round(fabric_gb * 1e9 / max(1, rays), 1) if fabric_gb else None,
         "tcc_hit_rate": traffic.get("tcc_hit_rate") if traffic else None,
-        # the unit this kernel's gathers queue at: the CU's vector-memory address path (one L1 tag look-up per clock); PMC
+        # the CU's vector-memory address path (one L1 tag look-up per clock); PMC
         "l1_address_unit_busy_frac": traffic.get("ta_busy_frac") if traffic else None,
         "l1_lookups_per_cu_clock": traffic.get("l1_lookups_per_cu_clock") if traffic else None,
         "valu_active_frac": traffic.get("valu_active_frac") if traffic else None,
         "reduce_ms_total": round(reduce_ms, 3),
-    }
+    })
+    return head
 
 
 def parse_args(argv=None):

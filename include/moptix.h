@@ -254,6 +254,9 @@ int moptix_reduce_time(moptix_context ctx, double* totalMs);
 /* debug/validation: copy the built BVH to host (nodes: nNodes*128 B four-child nodes, tris: nTriangles*48 B,
  * triPrimIds: nTriangles int32 = original face index of each record). Any pointer may be NULL. */
 int moptix_debug_read_accel(moptix_context ctx, void* nodes, void* tris, int32_t* triPrimIds);
+/* the same nodes in the 64-byte form the trace kernels fetch (nNodes*64 B: corner, grid exponents, 24 plane bytes, the four
+ * child references -- csrc/pt_types.h Node64); node i of this array stands for node i of moptix_debug_read_accel's. */
+int moptix_debug_read_nodes64(moptix_context ctx, void* nodes64);
 /* nearest-hit query for n rays (BVH-vs-brute-force tests): rays = n x {ox,oy,oz,dx,dy,dz,tmin,tmax};
  * outT[n], outPrim[n] (prim id: spheres, quads, triangles; -1 = miss). */
 int moptix_debug_trace(moptix_context ctx, const float* rays, int32_t n, float* outT, int32_t* outPrim);

@@ -108,7 +108,7 @@ DEVICE_SYMBOLS = [
     "moptix_validate", "moptix_launch", "moptix_render", "moptix_render_async", "moptix_sync",
     "moptix_render_counted", "moptix_set_partition", "moptix_set_option", "moptix_get_option",
     "moptix_accum_read", "moptix_accum_clear", "moptix_accum_device_ptr", "moptix_accum_bind",
-    "moptix_resolve_rgb8", "moptix_kernel_time", "moptix_reduce_time", "moptix_debug_read_accel", "moptix_debug_trace",
+    "moptix_resolve_rgb8", "moptix_kernel_time", "moptix_reduce_time", "moptix_debug_read_accel", "moptix_debug_read_nodes64", "moptix_debug_trace",
     "moptix_comm_unique_id", "moptix_comm_init", "moptix_comm_destroy", "moptix_gather_tiles", "moptix_reduce_frame",
     "moptix_packed_tile_floats", "moptix_pack_tiles", "moptix_unpack_tiles",
 ]
@@ -170,6 +170,7 @@ def device_lib():
         L.moptix_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.moptix_reduce_time.argtypes = [vp, C.POINTER(C.c_double)]
         L.moptix_debug_read_accel.argtypes = [vp, vp, vp, i32p]
+        L.moptix_debug_read_nodes64.argtypes = [vp, vp]
         L.moptix_debug_trace.argtypes = [vp, f32p, i32, f32p, i32p]
         u8p = C.POINTER(C.c_uint8)
         L.moptix_comm_unique_id.argtypes = [u8p]

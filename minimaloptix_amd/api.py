@@ -327,6 +327,13 @@ class Context:
                                                   prim.ctypes.data_as(C.POINTER(C.c_int32))))
         return nodes[:a.nNodes], tris[:a.nTriangles], prim[:a.nTriangles]
 
+    def debug_read_nodes64(self):
+        """The nodes as the trace kernels fetch them: [nNodes, 16] words (Node64: corner xyz, exponents, 6 plane words, 4 refs, pad)."""
+        a = self.accel_info()
+        nodes = np.zeros((max(1, a.nNodes), 16), np.uint32)
+        self._chk(self._L.moptix_debug_read_nodes64(self._h, nodes.ctypes.data))
+        return nodes[:a.nNodes]
+
     def debug_trace(self, rays):
         rays = np.ascontiguousarray(np.asarray(rays, np.float32).reshape(-1, 8))
         n = len(rays)

@@ -486,6 +486,15 @@ __global__ void k_emit(int ni, const int* __restrict__ left, const int* __restri
   nodes[newIndex[i]] = nd;
 }
 
+// 7c. the 64-byte form of the nodes; *bad counts nodes whose box is wider than the grid can span
+__global__ void k_compress(int n, const Node128* __restrict__ nodes, Node64* __restrict__ out, int* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Node64 c;
+  if (!compress_node(nodes[i], c)) atomicAdd(bad, 1);
+  out[i] = c;
+}
+
 template <class T> hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, sizeof(T) * (n ? n : 1)); }
 
 }  // namespace
@@ -493,6 +502,7 @@ template <class T> hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void*
 void lbvh_free(LbvhResult* r) {
   if (!r) return;
   if (r->nodes) (void)hipFree(r->nodes);
+  if (r->nodes64) (void)hipFree(r->nodes64);
   if (r->tris) (void)hipFree(r->tris);
   if (r->shade) (void)hipFree(r->shade);
   *r = LbvhResult();
@@ -596,6 +606,7 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
   if (n <= leafSize) {
     out->rootRef = make_leaf_ref(0, n); out->nNodes = 0; out->depth = 0;
     LB_CHECK(dmalloc(&out->nodes, 1));
+    LB_CHECK(dmalloc(&out->nodes64, 1));
   } else {
     LB_CHECK(hipMemsetAsync(arrivals, 0, sizeof(unsigned int) * (size_t)ni, stream));
     LB_CHECK(hipMemsetAsync(dDepth, 0, sizeof(int), stream));
@@ -615,11 +626,16 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
     out->nNodes = pinned[2] + pinned[3]; out->depth = pinned[4];
     LB_CHECK(dmalloc(&out->nodes, (size_t)out->nNodes));
     k_emit<<<grid_for(ni), kBlock, 0, stream>>>(ni, left, right, first, last, kept, newIndex, leafSize, leafLo, leafHi, ilo, ihi, out->nodes);
+    LB_CHECK(dmalloc(&out->nodes64, (size_t)out->nNodes));
+    LB_CHECK(hipMemsetAsync(dDepth, 0, sizeof(int), stream));
+    k_compress<<<grid_for(out->nNodes), kBlock, 0, stream>>>(out->nNodes, out->nodes, out->nodes64, dDepth);
+    LB_CHECK(hipMemcpyAsync(pinned + 4, dDepth, sizeof(int), hipMemcpyDeviceToHost, stream));
     out->rootRef = 0;
   }
   LB_CHECK(hipEventRecord(e1, stream));
   LB_CHECK(hipStreamSynchronize(stream));
   LB_CHECK(hipGetLastError());
+  if (out->nNodes > 0 && pinned[4] != 0) { err = hipErrorInvalidValue; goto done; }     // a node wider than 255 * 2^26 units (pt_lbvh.h compress_node)
   (void)hipEventElapsedTime(&out->buildMs, e0, e1);
   out->stackBound = wide_stack_bound(out->depth);
 

@@ -139,7 +139,7 @@ void fill_view(moptix_context c, SceneView& v) {
   v.shadowNearest = 0;
   for (const DevMaterial& m : c->mats) if (m.kind == MAT_DISNEY && m.brdfType == BRDF_GLASS) v.shadowNearest = 1;
   v.nTris = c->bvh.nTris; v.rootRef = c->bvh.nTris > 0 ? c->bvh.rootRef : kEmptyRef;
-  v.nodes = c->bvh.nodes; v.tris = c->bvh.tris; v.triShade = c->bvh.shade;
+  v.nodes = c->bvh.nodes; v.nodes64 = c->bvh.nodes64; v.tris = c->bvh.tris; v.triShade = c->bvh.shade;
   v.triUV = (c->anyUV && c->bvh.nTris > 0) ? c->dFaceUV.p : nullptr;
   v.nTextures = (int)c->textures.size(); v.textures = c->dTextures.p;
 }
@@ -811,6 +811,14 @@ int moptix_kernel_time(moptix_context c, double* totalMs, uint64_t* nLaunches, i
 int moptix_reduce_time(moptix_context c, double* totalMs) {
   if (!c || !totalMs) return MOPTIX_ERR_INVALID;
   *totalMs = c->reduceMs;
+  return MOPTIX_OK;
+}
+
+int moptix_debug_read_nodes64(moptix_context c, void* nodes64) {
+  if (!c || !nodes64) return MOPTIX_ERR_INVALID;
+  if (!c->accelBuilt) return fail(c, MOPTIX_ERR_STATE, "no acceleration structure");
+  HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  if (c->bvh.nNodes > 0) HIPCHK(c, hipMemcpy(nodes64, c->bvh.nodes64, sizeof(Node64) * c->bvh.nNodes, hipMemcpyDeviceToHost), "read nodes64");
   return MOPTIX_OK;
 }
 

@@ -225,16 +225,14 @@ PT_HD void planes4(const v4& p, float inv, float noi, float out[4]) {
 #define PT_STACK_ROOMY 1
 #endif
 // The slab tests, the sort and the pushes of one four-child node whose record is already in registers.
+// The sort and the pushes of one four-child node whose twenty-four plane distances are known.
 template <bool CNT, class Stack>
-PT_HD void node_step_with(const PathState& ps, Trav& tv, Stack& st, Counters& ct, const v4& lox, const v4& loy, const v4& loz,
-                          const v4& hix, const v4& hiy, const v4& hiz, int r0, int r1, int r2, int r3) {
+PT_HD void node_step_planes(const PathState& ps, Trav& tv, Stack& st, Counters& ct, const float ax[4], const float bx[4], const float ay[4],
+                            const float by[4], const float az[4], const float bz[4], int r0, int r1, int r2, int r3) {
   int r[4] = { r0, r1, r2, r3 };
   cnt<CNT>(ct.nodeFetches);
   const float kFar = 3.0e38f;
-  float ax[4], bx[4], ay[4], by[4], az[4], bz[4], t[4];
-  planes4(lox, tv.inv.x, tv.noi.x, ax); planes4(hix, tv.inv.x, tv.noi.x, bx);
-  planes4(loy, tv.inv.y, tv.noi.y, ay); planes4(hiy, tv.inv.y, tv.noi.y, by);
-  planes4(loz, tv.inv.z, tv.noi.z, az); planes4(hiz, tv.inv.z, tv.noi.z, bz);
+  float t[4];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -261,10 +259,43 @@ PT_HD void node_step_with(const PathState& ps, Trav& tv, Stack& st, Counters& ct
     trav_pop(tv, st);
   }
 }
+// The slab tests, the sort and the pushes of one four-child node whose 128-byte record is already in registers.
+template <bool CNT, class Stack>
+PT_HD void node_step_with(const PathState& ps, Trav& tv, Stack& st, Counters& ct, const v4& lox, const v4& loy, const v4& loz,
+                          const v4& hix, const v4& hiy, const v4& hiz, int r0, int r1, int r2, int r3) {
+  float ax[4], bx[4], ay[4], by[4], az[4], bz[4];
+  planes4(lox, tv.inv.x, tv.noi.x, ax); planes4(hix, tv.inv.x, tv.noi.x, bx);
+  planes4(loy, tv.inv.y, tv.noi.y, ay); planes4(hiy, tv.inv.y, tv.noi.y, by);
+  planes4(loz, tv.inv.z, tv.noi.z, az); planes4(hiz, tv.inv.z, tv.noi.z, bz);
+  node_step_planes<CNT>(ps, tv, st, ct, ax, bx, ay, by, az, bz, r0, r1, r2, r3);
+}
+// PT_NODE64=1: the node loop fetches the 64-byte form of the nodes (pt_types.h Node64): four look-ups per lane instead of
+// seven.  The decode is folded into the slab test: plane = corner + q * 2^e, so
+//   t = (plane - o) / d = q * (2^e / d) + (corner - o) / d = fma(q, ldexp(1/d, e), fma(corner, 1/d, -o/d))
+// -- per node three v_ldexp and three fma, per plane one v_cvt_f32_ubyteN and the fma the uncompressed form needs as well.
+#ifndef PT_NODE64
+#define PT_NODE64 1
+#endif
+PT_HD void planes4q(uint32_t w, float step, float base, float out[4]) {
+  out[0] = fma_((float)(w & 0xffu), step, base); out[1] = fma_((float)((w >> 8) & 0xffu), step, base);
+  out[2] = fma_((float)((w >> 16) & 0xffu), step, base); out[3] = fma_((float)(w >> 24), step, base);
+}
 template <bool CNT, class Stack>
 PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
+#if PT_NODE64
+  const Node64 n = load_const(sc.nodes64 + tv.node);
+  const float sx = __builtin_ldexpf(tv.inv.x, (int)(int8_t)(n.exps & 0xffu)), sy = __builtin_ldexpf(tv.inv.y, (int)(int8_t)((n.exps >> 8) & 0xffu)),
+              sz = __builtin_ldexpf(tv.inv.z, (int)(int8_t)((n.exps >> 16) & 0xffu));
+  const float cx = fma_(n.ox, tv.inv.x, tv.noi.x), cy = fma_(n.oy, tv.inv.y, tv.noi.y), cz = fma_(n.oz, tv.inv.z, tv.noi.z);
+  float ax[4], bx[4], ay[4], by[4], az[4], bz[4];
+  planes4q(n.q[0], sx, cx, ax); planes4q(n.q[3], sx, cx, bx);
+  planes4q(n.q[1], sy, cy, ay); planes4q(n.q[4], sy, cy, by);
+  planes4q(n.q[2], sz, cz, az); planes4q(n.q[5], sz, cz, bz);
+  node_step_planes<CNT>(ps, tv, st, ct, ax, bx, ay, by, az, bz, n.ref[0], n.ref[1], n.ref[2], n.ref[3]);
+#else
   const Node128 npv = load_const(sc.nodes + tv.node);
   node_step_with<CNT>(ps, tv, st, ct, npv.lox, npv.loy, npv.loz, npv.hix, npv.hiy, npv.hiz, npv.ref[0], npv.ref[1], npv.ref[2], npv.ref[3]);
+#endif
 }
 
 #if defined(__HIPCC__)

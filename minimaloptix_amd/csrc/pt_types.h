@@ -59,6 +59,20 @@ struct alignas(128) Node128 {
 };
 static_assert(sizeof(Node128) == 128, "Node128 must be 128 bytes");
 
+// The same node in 64 bytes, the form the trace kernels fetch (PT_NODE64, pt_path.h): a lane's own node costs the L1 four
+// look-ups instead of seven, and the node array of a scene takes half the L2.  The children's boxes sit on a 256-step grid
+// laid over the node's own box: plane = corner + q * 2^e per axis, rounded OUTWARDS when the node is written
+// (pt_lbvh.h compress_node), so a quantised box contains the box it stands for and the traversal can only enter more
+// boxes, never fewer: which boxes are entered changes the amount of work, not a result (rule D5).
+struct alignas(64) Node64 {
+  float ox, oy, oz;     // lower corner of the node's box (minus the margin compress_node adds)
+  uint32_t exps;        // bytes 0..2: e of axes x, y, z (signed); byte 3: children in use
+  uint32_t q[6];        // lox loy loz hix hiy hiz: byte k = child k, in grid steps from the corner
+  int ref[4];           // as Node128::ref
+  int pad[2];
+};
+static_assert(sizeof(Node64) == 64, "Node64 must be 64 bytes");
+
 struct alignas(16) Tri48 {
   v3 p0; int mat;        // material id of the face
   v3 e0; int prim;       // e0 = p1-p0 ; prim = original face index (upload order)
@@ -146,6 +160,7 @@ struct SceneView {
   int shadowNearest;              // the scene has a Disney GLASS material: shadow rays are decided by their NEAREST any-hit surface (pt_path.h)
   int nTris; int rootRef;         // rootRef: node index, leaf ref or kEmptyRef
   const Node128* nodes; const Tri48* tris; const TriShade* triShade;
+  const Node64* nodes64;          // the nodes again, compressed (same indices): what the kernels fetch when PT_NODE64 is on
   const TriUV* triUV;             // per face in upload order, or nullptr (no mesh has texcoords)
   int nTextures; const DevTexture* textures;
 };

@@ -32,7 +32,7 @@ class HostsimScene(C.Structure):
 
 class HostsimBvhOut(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("tris", C.c_void_p), ("triPrim", C.POINTER(C.c_int32)),
-                ("nNodes", C.c_int32), ("rootRef", C.c_int32), ("depth", C.c_int32)]
+                ("nNodes", C.c_int32), ("rootRef", C.c_int32), ("depth", C.c_int32), ("nodes64", C.c_void_p)]
 
 
 def hostsim_lib():
@@ -95,7 +95,20 @@ def hostsim_render(hs, seeds, leaf_size=4, accum=None):
     return accum, out
 
 
-def hostsim_bvh(hs, leaf_size=4, builder=1):
+def node64_boxes(n64):
+    """Decodes [n, 16]-word Node64 records as the kernels do (plane = fma(q, 2^e, corner), pt_lbvh.h node64_plane): returns
+    (boxes [n, 6, 4] float32 in the order lox loy loz hix hiy hiz x child, refs [n, 4] int32, count [n])."""
+    n64 = np.ascontiguousarray(n64, np.uint32)
+    corner = n64[:, 0:3].view(np.float32).astype(np.float64)
+    e = ((n64[:, 3:4] >> (8 * np.arange(3, dtype=np.uint32))) & 0xff).astype(np.int8).astype(np.int32)
+    step = np.ldexp(1.0, e)
+    q = ((n64[:, 4:10, None] >> (8 * np.arange(4, dtype=np.uint32))) & 0xff).astype(np.float64)      # [n, 6, 4]
+    ax = np.array([0, 1, 2, 0, 1, 2])
+    boxes = (q * step[:, ax, None] + corner[:, ax, None]).astype(np.float32)      # one rounding, as the fma
+    return boxes, n64[:, 10:14].view(np.int32), (n64[:, 3] >> 24).astype(np.int32)
+
+
+def hostsim_bvh(hs, leaf_size=4, builder=1, want_nodes64=False):
     """builder: 0 = Morton radix tree, 1 = binned SAH (the device default; moptix option "builder")."""
     hostsim_lib().hostsim_set_builder(int(builder))
     s, keep = _hostsim_scene(hs)
@@ -103,9 +116,13 @@ def hostsim_bvh(hs, leaf_size=4, builder=1):
     nodes = np.zeros((nf, 32), np.uint32); tris = np.zeros((nf, 12), np.uint32); prim = np.zeros(nf, np.int32)
     out = HostsimBvhOut()
     out.nodes, out.tris, out.triPrim = nodes.ctypes.data, tris.ctypes.data, prim.ctypes.data_as(C.POINTER(C.c_int32))
+    n64 = np.zeros((nf, 16), np.uint32)
+    out.nodes64 = n64.ctypes.data if want_nodes64 else None
     rc = hostsim_lib().hostsim_build_bvh(C.byref(s), leaf_size, C.byref(out))
     hostsim_lib().hostsim_set_builder(1)
     assert rc == 0
+    if want_nodes64:
+        return nodes[:out.nNodes], tris[:s.nFaces], prim[:s.nFaces], out.rootRef, out.depth, n64[:out.nNodes]
     return nodes[:out.nNodes], tris[:s.nFaces], prim[:s.nFaces], out.rootRef, out.depth
 
 

@@ -41,6 +41,7 @@ struct hostsim_scene {
 struct hostsim_bvh_out {      // caller-allocated: nodes >= max(1,nFaces-1)*128 B, tris nFaces*48 B
   void* nodes; void* tris; int32_t* triPrim;
   int32_t nNodes, rootRef, depth;
+  void* nodes64;                // may be NULL: the same nodes compressed, nNodes*64 B
 };
 
 }  // extern "C"
@@ -48,7 +49,7 @@ struct hostsim_bvh_out {      // caller-allocated: nodes >= max(1,nFaces-1)*128 
 namespace {
 
 struct HostBVH {
-  std::vector<Node128> nodes; std::vector<Tri48> tris; std::vector<TriShade> shade;
+  std::vector<Node128> nodes; std::vector<Node64> nodes64; std::vector<Tri48> tris; std::vector<TriShade> shade;
   int rootRef = kEmptyRef; int depth = 0;
 };
 
@@ -133,7 +134,7 @@ static int g_builder = 1;     // 0 = Morton radix tree (Karras), 1 = binned SAH 
 
 static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   const int n = s.nFaces;
-  out.nodes.clear(); out.tris.clear(); out.shade.clear(); out.rootRef = kEmptyRef; out.depth = 0;
+  out.nodes.clear(); out.nodes64.clear(); out.tris.clear(); out.shade.clear(); out.rootRef = kEmptyRef; out.depth = 0;
   if (n <= 0) return;
   std::vector<v3> lo(n), hi(n), cen(n);
   v3 clo = mk3(1e37f, 1e37f, 1e37f), chi = mk3(-1e37f, -1e37f, -1e37f);
@@ -247,6 +248,9 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   }
   out.rootRef = 0;
   out.depth = subtree_depth(out.nodes, 0);
+  out.nodes64.resize(out.nodes.size());
+  for (size_t i = 0; i < out.nodes.size(); i++)
+    if (!compress_node(out.nodes[i], out.nodes64[i])) { fprintf(stderr, "[hostsim] node %zu is wider than the 64-byte form can hold\n", i); abort(); }
 }
 
 struct LocalStack {
@@ -284,7 +288,7 @@ static void make_scene(const hostsim_scene& s, int leafSize, HostScene& hs) {
   for (int i = 0; i < s.nSpheres; i++) if (hs.mats[s.sphereMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
   for (int i = 0; i < s.nQuads; i++) if (hs.mats[s.quadMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
   v.nTris = s.nFaces; v.rootRef = hs.bvh.rootRef;
-  v.nodes = hs.bvh.nodes.data(); v.tris = hs.bvh.tris.data(); v.triShade = hs.bvh.shade.data();
+  v.nodes = hs.bvh.nodes.data(); v.nodes64 = hs.bvh.nodes64.data(); v.tris = hs.bvh.tris.data(); v.triShade = hs.bvh.shade.data();
   bool anyUV = false;
   for (int f = 0; f < s.nFaces; f++) {
     TriUV uv; memset(&uv, 0, sizeof(uv));
@@ -311,6 +315,7 @@ int hostsim_build_bvh(const hostsim_scene* s, int leafSize, hostsim_bvh_out* out
   HostBVH b; build_lbvh(*s, leafSize, b);
   out->nNodes = (int)b.nodes.size(); out->rootRef = b.rootRef; out->depth = b.depth;
   if (out->nodes && !b.nodes.empty()) memcpy(out->nodes, b.nodes.data(), b.nodes.size() * sizeof(Node128));
+  if (out->nodes64 && !b.nodes64.empty()) memcpy(out->nodes64, b.nodes64.data(), b.nodes64.size() * sizeof(Node64));
   if (out->tris && !b.tris.empty()) memcpy(out->tris, b.tris.data(), b.tris.size() * sizeof(Tri48));
   if (out->triPrim) for (size_t i = 0; i < b.tris.size(); i++) out->triPrim[i] = b.tris[i].prim;
   return 0;

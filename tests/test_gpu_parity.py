@@ -114,14 +114,16 @@ def test_device_lbvh_equals_host_mirror(gpu_ctx, leaf, builder):
     try:
         gpu_ctx.load(hs)
         nodes, tris, prim = gpu_ctx.debug_read_accel()
+        n64 = gpu_ctx.debug_read_nodes64()
     finally:
         gpu_ctx.set_option("builder", 1)
-    hn, ht, hp, root, depth = hostsim_bvh(hs, leaf, builder)
+    hn, ht, hp, root, depth, h64 = hostsim_bvh(hs, leaf, builder, want_nodes64=True)
     info = gpu_ctx.accel_info()
     assert info.nNodes == len(hn) and info.treeDepth == depth
     assert np.array_equal(prim, hp)
     assert np.array_equal(tris[:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]], ht[:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]])
     assert np.array_equal(nodes[:, :29], hn[:, :29])                     # boxes, refs and child count of every Node128
+    assert np.array_equal(n64[:, :14], h64[:, :14])                      # and of the 64-byte form the kernels fetch
     gpu_ctx.set_option("leaf_size", 4)
 
 

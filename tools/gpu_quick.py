@@ -19,7 +19,7 @@ for _ in range(int(os.environ.get("WARM", "0"))):   # history for the tile order
     ctx.accum_clear(); ctx.render(seeds)
 ctx.accum_clear(); st = ctx.render_counted(seeds)
 rays = st.rays
-B = 128 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
+B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * W * H
 best = 1e9
 for rep in range(3):
     ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); ms, n = ctx.kernel_time(); best = min(best, ms)
