@@ -28,7 +28,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-NODE_BYTES = 64             # the node record the kernels fetch (csrc/pt_types.h Node64)
+NODE_BYTES = 64             # the node record the packet kernel fetches on coffee (csrc/pt_types.h Node64; get_option "node_format_used" says which)
 VALU_ISSUE_PEAK_G = 256 * 4 * 2.4 / 4.0     # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 vector instruction per SIMD every 4 clocks at 2.4 GHz (same guide)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
 GATHER_CEILING_FILE = os.path.join("profiles", "r03_gather_ceiling.txt")    # output of tools/micro/gather on MI355X
@@ -48,12 +48,12 @@ def source_hash(repo):
     return h.hexdigest()[:16]
 
 
-def algorithmic_bytes(st, pixels):
-    """B = 64*N_node + 48*N_tri + 108*N_hit + 72*N_lightLoads + 24*N_accum.  N_node counts fetches of
-    four-child nodes in their 64-byte form (csrc/pt_types.h Node64: what the kernels read since round 3; the 128-byte
-    form of rounds 1-2 is only the builder's output now).  N_accum is counted per pixel per launch batch (the per-sample
-    buffer traffic is not claimed)."""
-    return NODE_BYTES * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * pixels
+def algorithmic_bytes(st, pixels, node_bytes=NODE_BYTES):
+    """B = NODE*N_node + 48*N_tri + 108*N_hit + 72*N_lightLoads + 24*N_accum.  N_node counts fetches of
+    four-child nodes; NODE is the record the kernel read: 64 bytes (csrc/pt_types.h Node64, round 3) where the scene's own
+    paths say the compressed form is cheaper -- coffee --, else the 128-byte form of rounds 1-2.  N_accum is counted per
+    pixel per launch batch (the per-sample buffer traffic is not claimed)."""
+    return node_bytes * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * pixels
 
 
 def gather_ceilings(repo):
@@ -112,7 +112,7 @@ def read_traffic(repo):
     return t
 
 
-def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per_ray, rays, reduce_ms, kernel, traffic, ceil):
+def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per_ray, rays, reduce_ms, kernel, traffic, ceil, node_bytes=NODE_BYTES):
     """The dominant kernel against the roof that binds it.
 
     What binds it: the issue rate of the vector ALUs at the three waves per SIMD the kernel's
@@ -130,7 +130,7 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
     `hbm_frac` (bytes that really crossed the fabric, PMC) and as the SURVEY figure `algorithmic_frac_of_hbm`."""
     launch_s = launch_ms * 1e-3
     fabric_gb = traffic.get("traffic_GB_per_launch") if traffic else None
-    gpeak = ceil["l2_%d" % NODE_BYTES] if ceil else None
+    gpeak = ceil["l2_%d" % node_bytes] if ceil else None
     valu = (traffic.get("SQ") or {}).get("SQ_INSTS_VALU") if traffic else None
     lanes = None
     if traffic and (traffic.get("SQ") or {}).get("SQ_THREAD_CYCLES_VALU") and traffic["SQ"].get("SQ_ACTIVE_INST_VALU"):
@@ -148,13 +148,13 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
     head.update({
         "valu_instructions_per_ray": round(valu / max(1, rays), 2) if valu else None,      # wave-level instructions per ray traced
         "valu_lane_utilisation": lanes,
-        "kernel": kernel, "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
+        "kernel": kernel, "node_bytes": int(node_bytes), "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
         "algorithmic_bytes_per_launch": int(bytes_per_launch), "bytes_per_ray": round(bytes_per_ray, 1),
         "algorithmic_GBps": round(achieved_gbs, 1), "algorithmic_frac_of_hbm": round(achieved_gbs / HBM_PEAK_GBS, 4),
         "gather_peak_GBps": round(gpeak, 1) if gpeak else None, "gather_frac": round(achieved_gbs / gpeak, 4) if gpeak else None,
-        "gather_peak_source": GATHER_CEILING_FILE + " (tools/micro/gather.hip: dependent per-lane gathers of %d-B records, 3.1 MB table, best over occupancies)" % NODE_BYTES,
-        "gather_peak_at_kernel_occupancy_GBps": round(ceil["l2_%d_at_12_waves" % NODE_BYTES], 1) if ceil and ("l2_%d_at_12_waves" % NODE_BYTES) in ceil else None,
-        "infinity_cache_gather_GBps": round(ceil["ic_%d" % NODE_BYTES], 1) if ceil and ("ic_%d" % NODE_BYTES) in ceil else None,
+        "gather_peak_source": GATHER_CEILING_FILE + " (tools/micro/gather.hip: dependent per-lane gathers of %d-B records, 3.1 MB table, best over occupancies)" % node_bytes,
+        "gather_peak_at_kernel_occupancy_GBps": round(ceil["l2_%d_at_12_waves" % node_bytes], 1) if ceil and ("l2_%d_at_12_waves" % node_bytes) in ceil else None,
+        "infinity_cache_gather_GBps": round(ceil["ic_%d" % node_bytes], 1) if ceil and ("ic_%d" % node_bytes) in ceil else None,
         "hbm_peak_GBps": HBM_PEAK_GBS,
         "hbm_frac": round(fabric_gb / launch_s / HBM_PEAK_GBS, 4) if fabric_gb else None,
         # FETCH_SIZE tallies 64 B per fabric read request; a request of this kernel's gathers fills a 128-byte line (calibrated with
@@ -271,7 +271,8 @@ class GpuFrame:
         self.accum.zero_(); self.sync()
         st = self.ctx.render_counted(self.seeds)
         px = a.width * a.height if self.sample_split else len(self.D.tile_pixel_indices(a.width, a.height, self.part_rank, self.part_n))
-        return st.rays, algorithmic_bytes(st, px)
+        self.node_bytes = self.ctx.get_option("node_format_used") if self.ctx.get_option("kernel_variant_used") == 4 else 128
+        return st.rays, algorithmic_bytes(st, px, self.node_bytes)
 
     def collect(self, j):                                               # the frame's one collective
         a = self.a
@@ -439,7 +440,7 @@ def run_rank(a, frame_cls=GpuFrame):
         achieved = my_bytes / passes_per_step / max(launch_ms * 1e-3, 1e-12) / 1e9        # GB/s, rank 0's trace kernel
         d = fr.describe()
         roof = roofline_block(achieved, launch_ms, nlaunch, my_bytes // passes_per_step, my_bytes / max(1, my_rays), my_rays,
-                              reduce_ms, d.pop("kernel"), fr.traffic(), gather_ceilings(REPO))
+                              reduce_ms, d.pop("kernel"), fr.traffic(), gather_ceilings(REPO), getattr(fr, "node_bytes", NODE_BYTES))
         out = {
             "metric": "Mrays/s (primary+bounce+shadow rays traced per second, coffee.obj 1920x1080 256spp)",
             "value": round(total_rays / (dt / a.steps) / 1e6, 2), "unit": "Mrays/s",

@@ -113,7 +113,7 @@ typedef struct moptix_accel_info {
   uint32_t nTriangles, nNodes, maxLeafSize, treeDepth;
   float buildMs;                 /* wall time of the last acceleration build between two HIP events on the launch stream: its kernels plus the
                                     host round trips between them (the binned-SAH builder reads one node count per level back) */
-  uint64_t nodeBytes, triBytes;
+  uint64_t nodeBytes, triBytes;  /* nodeBytes: both forms of the nodes, nNodes x (128 + 64) */
 } moptix_accel_info;
 
 /* ---- lifecycle: Context::create()/setRayTypeCount/setEntryPointCount/setStackSize
@@ -210,6 +210,11 @@ int moptix_unpack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, const 
  *                      While it has not been set: 4 for launches of >= 1e6 samples and >= 16 seeds on scenes that are not
  *                      mostly glass ("auto_packet" = 0 turns that off), else 3; scenes without triangles: see "analytic_queue"
  *   "builder"          1 binned-SAH topology over the Morton order (default), 0 Morton radix tree
+ *   "node_format"      variant 4: the node record the trace kernel fetches -- 128 = four child boxes in binary32 (one L2 line), 64 =
+ *                      the same boxes on a 256-step grid over the node's box, rounded outwards (half a line: 4 L1 look-ups per
+ *                      node step instead of 7, boxes up to a grid step larger), 0 (default) = whichever is cheaper for this scene
+ *                      seen from this camera: decided at the first render after a build by walking one path per pixel of a
+ *                      128-pixel-wide grid under both (get_option "node_format_used" tells the verdict)
  *   "slots_in_use"     path slots per 512-slot pool that carry a path (-1 = chosen per launch: 448 for variant 4 launches
  *                      under 1e8 samples, else all); the others are what deep paths borrow, see "aux_depth"
  *   "aux_depth"        variant 4: a path this deep (default 16; 0 = never) traces the shadow rays of each hit in slots
@@ -254,7 +259,7 @@ int moptix_reduce_time(moptix_context ctx, double* totalMs);
 /* debug/validation: copy the built BVH to host (nodes: nNodes*128 B four-child nodes, tris: nTriangles*48 B,
  * triPrimIds: nTriangles int32 = original face index of each record). Any pointer may be NULL. */
 int moptix_debug_read_accel(moptix_context ctx, void* nodes, void* tris, int32_t* triPrimIds);
-/* the same nodes in the 64-byte form the trace kernels fetch (nNodes*64 B: corner, grid exponents, 24 plane bytes, the four
+/* the same nodes in the 64-byte form the trace kernels fetch (nNodes*64 B: corner, grid steps, 24 plane bytes, the four
  * child references -- csrc/pt_types.h Node64); node i of this array stands for node i of moptix_debug_read_accel's. */
 int moptix_debug_read_nodes64(moptix_context ctx, void* nodes64);
 /* nearest-hit query for n rays (BVH-vs-brute-force tests): rays = n x {ox,oy,oz,dx,dy,dz,tmin,tmax};

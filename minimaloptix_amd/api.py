@@ -328,7 +328,7 @@ class Context:
         return nodes[:a.nNodes], tris[:a.nTriangles], prim[:a.nTriangles]
 
     def debug_read_nodes64(self):
-        """The nodes as the trace kernels fetch them: [nNodes, 16] words (Node64: corner xyz, exponents, 6 plane words, 4 refs, pad)."""
+        """The nodes as the trace kernels fetch them: [nNodes, 16] words (Node64: corner xyz, step xyz, 6 plane words, 4 refs)."""
         a = self.accel_info()
         nodes = np.zeros((max(1, a.nNodes), 16), np.uint32)
         self._chk(self._L.moptix_debug_read_nodes64(self._h, nodes.ctypes.data))

@@ -89,6 +89,9 @@ size_t packetkernel_cold_bytes(int nBlocks);
 size_t packetkernel_overflow_ints(int nBlocks, int ovfDepth);
 hipError_t launch_packetkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading);
 hipError_t launch_debug_trace(hipStream_t stream, const SceneView& sc, const float* dRays, int n, float* dT, int* dPrim, int* stackOverflow);
+// node steps and triangle tests of one sample per pixel of sc.width x sc.height, paths cut at depth 6, under one node format
+// (dOut[0..1] += ; megakernel.hip k_probe_paths)
+hipError_t launch_probe_paths(hipStream_t stream, const SceneView& sc, int launchSeed, bool node64, unsigned long long* dOut, int* stackOverflow);
 hipError_t launch_resolve_rgb8(hipStream_t stream, float* accum, int width, int height, float nAccumulation, int clearBuffer, uint8_t* dOut);
 
 }  // namespace pt

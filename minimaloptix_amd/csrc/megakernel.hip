@@ -169,6 +169,42 @@ __global__ void __launch_bounds__(kBlockThreads) k_debug_trace(SceneView sc, con
   outT[i] = tv.tbest; outPrim[i] = tv.bestPrim;
 }
 
+// Probe of a node format (first render after a build, option node_format = 0): the scene's own paths.  One thread per pixel
+// of a coarse grid over the camera's view (sc.width x sc.height here are the grid's, so the primary rays fan out over the same
+// frustum) runs the per-ray path state machine for one sample -- camera ray, closest hit, three shadow rays, bounce -- until
+// the path ends or is kProbeDepth deep, walking the tree in the format under test.  out[0] += node steps, out[1] += triangle
+// tests.  Counts, not times: the same scene, camera and parameters give the same verdict on every run.
+constexpr int kProbeDepth = 6;
+template <bool N64>
+__global__ void __launch_bounds__(kBlockThreads) k_probe_paths(SceneView sc, int launchSeed, unsigned long long* out, int* stackOverflow) {
+  __shared__ int ldsStack[kWavesPerBlock * kLdsStack * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  LaneStack st;
+  st.lds = ldsStack + wave * (kLdsStack * 64) + lane;
+  st.ovfStride = gridDim.x * kBlockThreads;
+  st.ovf = stackOverflow ? stackOverflow + i : nullptr;
+  Counters ct = {};
+  if (i < sc.width * sc.height) {
+    PathState ps = {};
+    ps.pixel = i; ps.item = 0; ps.accum = mk3(0, 0, 0); ps.N = mk3(0, 0, 1); ps.V = mk3(0, 0, 1);
+    Trav tv = {};
+    tv.node = kTravDone; tv.bestPrim = -1; tv.bestTri = -1; tv.att = mk3(1, 1, 1);
+    begin_sample<true>(sc, ps, launchSeed, ct);
+    while (ps.mode != M_DONE && ps.mode != M_NEW_SAMPLE && ps.depth <= kProbeDepth) {
+      if (ps.mode == M_TRACE) {
+        trav_begin<true>(sc, ps, tv, ct);
+        while (tv.node != kTravDone) trav_step<true, N64>(sc, ps, tv, st, ct);
+        ps.mode = M_RESULT;
+      } else if (ps.mode == M_RESULT) on_result<true>(sc, ps, tv, ct);
+      else if (ps.mode == M_LIGHTS) on_lights<true>(sc, ps, ct);
+      else break;
+    }
+  }
+  const uint32_t nf = wave_sum(ct.nodeFetches), tt = wave_sum(ct.triTests);
+  if (lane == 0) { atomicAdd(&out[0], (unsigned long long)nf); atomicAdd(&out[1], (unsigned long long)tt); }
+}
+
 // updateContent (MinimalOptiX.cpp:43-66): normalise, clamp, flip rows, 8-bit, optional clear.
 // QColor::setRedF stores qRound(v*65535) and QImage::Format_RGB888 keeps its high byte.
 __global__ void k_resolve_rgb8(float* accum, int width, int height, float nAccumulation, int clearBuffer, uint8_t* out) {
@@ -204,6 +240,13 @@ hipError_t launch_megakernel(hipStream_t stream, const LaunchArgs& a, int nBlock
 hipError_t launch_debug_trace(hipStream_t stream, const SceneView& sc, const float* dRays, int n, float* dT, int* dPrim, int* stackOverflow) {
   const int blocks = (n + kBlockThreads - 1) / kBlockThreads;
   k_debug_trace<<<blocks, kBlockThreads, 0, stream>>>(sc, dRays, n, dT, dPrim, stackOverflow);
+  return hipGetLastError();
+}
+
+hipError_t launch_probe_paths(hipStream_t stream, const SceneView& sc, int launchSeed, bool node64, unsigned long long* dOut, int* stackOverflow) {
+  const int blocks = (sc.width * sc.height + kBlockThreads - 1) / kBlockThreads;
+  if (node64) k_probe_paths<true><<<blocks, kBlockThreads, 0, stream>>>(sc, launchSeed, dOut, stackOverflow);
+  else        k_probe_paths<false><<<blocks, kBlockThreads, 0, stream>>>(sc, launchSeed, dOut, stackOverflow);
   return hipGetLastError();
 }
 

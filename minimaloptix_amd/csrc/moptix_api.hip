@@ -84,6 +84,10 @@ struct moptix_context_t {
 
   std::vector<int> seedStaging;
   int optWatchdogMs = 600000;
+  int optNodeFormat = 0;             // the node record the packet kernel fetches (pt_types.h): 64, 128, or 0 = whichever costs this scene less (choose_node_format)
+  int nodeFormatUsed = 128;          // the verdict for this build (get_option "node_format_used")
+  bool formatDecided = false;
+  unsigned long long probeCounts[4] = { 0, 0, 0, 0 };     // node steps, triangle tests of the probe rays under Node128; the same under Node64
   int optFastShading = 0;
   int optBuilder = 1;
   int optAnalyticQueue = -1;          // -1 = by primitive count
@@ -139,9 +143,52 @@ void fill_view(moptix_context c, SceneView& v) {
   v.shadowNearest = 0;
   for (const DevMaterial& m : c->mats) if (m.kind == MAT_DISNEY && m.brdfType == BRDF_GLASS) v.shadowNearest = 1;
   v.nTris = c->bvh.nTris; v.rootRef = c->bvh.nTris > 0 ? c->bvh.rootRef : kEmptyRef;
-  v.nodes = c->bvh.nodes; v.nodes64 = c->bvh.nodes64; v.tris = c->bvh.tris; v.triShade = c->bvh.shade;
+  v.nodes = c->bvh.nodes; v.nodes64 = c->nodeFormatUsed == 64 ? c->bvh.nodes64 : nullptr; v.tris = c->bvh.tris; v.triShade = c->bvh.shade;
   v.triUV = (c->anyUV && c->bvh.nTris > 0) ? c->dFaceUV.p : nullptr;
   v.nTextures = (int)c->textures.size(); v.textures = c->dTextures.p;
+}
+
+// Which node record the packet kernel fetches for this scene.  The 64-byte form saves three of seven look-ups per node step but
+// its boxes are a grid step larger.  Curved meshes hardly notice (coffee: +2 % node steps, +2 % triangle tests, frame -2.7 %);
+// a ray that leaves a large axis-aligned face does -- the face's exact box is thinner than tmin and culls itself, its quantised
+// box is a grid step of the PARENT thick and the ray starts inside it: the dining-room stand-in, whose walls are two triangles
+// each, tests 17 % more triangles and loses 6 %.  Static measures of the tree (surface-area inflation: 0.3 % for the dining
+// room, 0.7 % for coffee) and synthetic rays miss this, so the scene is asked with its own paths: one sample per pixel of a
+// 128-pixel-wide grid over the camera's view, cut at depth 6, walked under both forms; the counts are priced with the per-step
+// costs fitted to coffee, the coffee pot and the dining room (a triangle test with its share of the leaf visit = 3.5 node
+// steps of the 128-byte form; a 64-byte step = 0.82 of one).  Decided at the first render after a build; a later change of
+// camera keeps the verdict.
+constexpr int kProbeWidth = 128;
+int choose_node_format(moptix_context c) {
+  c->formatDecided = true;
+  c->nodeFormatUsed = 128;
+  for (auto& v : c->probeCounts) v = 0;
+  if (c->bvh.nNodes <= 0) return MOPTIX_OK;
+  if (c->optNodeFormat != 0) { c->nodeFormatUsed = c->optNodeFormat; return MOPTIX_OK; }
+  SceneView v; fill_view(c, v);
+  v.nodes64 = c->bvh.nodes64;
+  const int w = std::min(kProbeWidth, v.width), h = std::max(1, (int)((long long)v.height * w / std::max(1, v.width)));
+  v.width = w; v.height = h;
+  const size_t threads = ((size_t)w * h + 255) / 256 * 256;
+  unsigned long long* dOut = nullptr; int* dOvf = nullptr;
+  hipError_t e = hipMalloc((void**)&dOut, 4 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemsetAsync(dOut, 0, 4 * sizeof(unsigned long long), c->stream);
+  if (e == hipSuccess && c->bvh.stackBound > megakernel_lds_stack_entries())
+    e = hipMalloc((void**)&dOvf, sizeof(int) * threads * (size_t)(c->bvh.stackBound - megakernel_lds_stack_entries() + 1));
+  if (e == hipSuccess) e = launch_probe_paths(c->stream, v, 0, false, dOut, dOvf);
+  if (e == hipSuccess) e = launch_probe_paths(c->stream, v, 0, true, dOut + 2, dOvf);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->probeCounts, dOut, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (dOut) (void)hipFree(dOut);
+  if (dOvf) (void)hipFree(dOvf);
+  if (e != hipSuccess) return hipFail(c, e, "node format probe");
+  const double cost128 = (double)c->probeCounts[0] + 3.5 * (double)c->probeCounts[1];
+  const double cost64 = 0.82 * (double)c->probeCounts[2] + 3.5 * (double)c->probeCounts[3];
+  c->nodeFormatUsed = cost64 < cost128 ? 64 : 128;
+  if (getenv("MOPTIX_DEBUG"))
+    fprintf(stderr, "[moptix] node format probe (%dx%d paths): 128-byte nodes %llu steps %llu triangle tests, 64-byte %llu / %llu -> %d\n", w, h,
+            c->probeCounts[0], c->probeCounts[1], c->probeCounts[2], c->probeCounts[3], c->nodeFormatUsed);
+  return MOPTIX_OK;
 }
 
 int check_ready(moptix_context c) {
@@ -202,6 +249,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   if ((rc = moptix_sync(c)) != MOPTIX_OK) return rc;     // one batch in flight at a time
   if ((rc = ensure_accum(c)) != MOPTIX_OK) return rc;
   if (nSeeds == 0) return MOPTIX_OK;
+  if (!c->formatDecided && (rc = choose_node_format(c)) != MOPTIX_OK) return rc;
 
   LaunchArgs a;
   memset(&a, 0, sizeof(a));
@@ -646,6 +694,7 @@ int moptix_build_accel(moptix_context c, const char* kind) {
     HIPCHK(c, lbvh_build(c->stream, c->dFacePos.p, c->dFaceNrm.p, c->dFaceHasNrm.p, c->dFaceMat.p, nFaces, c->optLeafSize, c->optBuilder, &c->bvh), "LBVH build");
   }
   HIPCHK(c, hipStreamSynchronize(c->stream), "sync after upload");
+  c->formatDecided = false;            // choose_node_format at the next render: it needs the camera
   c->sceneDirty = false; c->accelBuilt = true;
   c->tileHistoryTiles = -1;            // new scene: forget which tiles had deep paths
   return MOPTIX_OK;
@@ -656,7 +705,7 @@ int moptix_get_accel_info(moptix_context c, moptix_accel_info* out) {
   memset(out, 0, sizeof(*out));
   out->nTriangles = (uint32_t)c->bvh.nTris; out->nNodes = (uint32_t)c->bvh.nNodes; out->maxLeafSize = (uint32_t)c->bvh.leafSize;
   out->treeDepth = (uint32_t)c->bvh.depth; out->buildMs = c->bvh.buildMs;
-  out->nodeBytes = (uint64_t)c->bvh.nNodes * sizeof(Node128); out->triBytes = (uint64_t)c->bvh.nTris * sizeof(Tri48);
+  out->nodeBytes = (uint64_t)c->bvh.nNodes * (sizeof(Node128) + sizeof(Node64)); out->triBytes = (uint64_t)c->bvh.nTris * sizeof(Tri48);
   return MOPTIX_OK;
 }
 
@@ -717,6 +766,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "slots_in_use")) { if (value < -1 || value > 512) return fail(c, MOPTIX_ERR_INVALID, "slots_in_use in [-1,512]"); c->optSlotsInUse = value; }
   else if (!strcmp(name, "builder")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "builder in {0,1}"); if (value != c->optBuilder) c->accelBuilt = false; c->optBuilder = value; }
   else if (!strcmp(name, "fast_shading")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "fast_shading in {0,1}"); c->optFastShading = value; }
+  else if (!strcmp(name, "node_format")) { if (value != 0 && value != 64 && value != 128) return fail(c, MOPTIX_ERR_INVALID, "node_format in {0,64,128}"); if (value != c->optNodeFormat) c->formatDecided = false; c->optNodeFormat = value; }
   else if (!strcmp(name, "watchdog_ms")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "watchdog_ms >= 1"); c->optWatchdogMs = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
@@ -734,6 +784,8 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "starve_lanes")) *value = c->optStarveLanes;
   else if (!strcmp(name, "tile_major")) *value = c->optTileMajor;
   else if (!strcmp(name, "watchdog_ms")) *value = c->optWatchdogMs;
+  else if (!strcmp(name, "node_format")) *value = c->optNodeFormat;
+  else if (!strcmp(name, "node_format_used")) *value = c->nodeFormatUsed;
   else if (!strcmp(name, "fast_shading")) *value = c->optFastShading;
   else if (!strcmp(name, "builder")) *value = c->optBuilder;
   else if (!strcmp(name, "aux_depth")) *value = c->optAuxDepth;

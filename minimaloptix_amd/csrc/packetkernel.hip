@@ -213,7 +213,7 @@ struct SlotSink {
 
 // NEAR: the scene has a Disney GLASS material, shadow rays keep their nearest any-hit candidate (pt_path.h, rule D5).  A template
 // parameter so that scenes without one -- the benchmark scene -- run code in which that logic does not exist.
-template <bool CNT, bool SHARED, bool FAST = false, bool NEAR = false>
+template <bool CNT, bool SHARED, bool FAST = false, bool NEAR = false, bool N64 = false>
 __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(const LaunchArgs a) {
   constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
   constexpr int RC = ring_capacity(NS);                  // ring capacity (power of two >= NS)
@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
 #if PT_QUAD_FETCH
         trav_node_step_quad<CNT>(sc, nray, ntv, st, ct, atNode);
 #else
-        if (atNode) trav_node_step<CNT>(sc, nray, ntv, st, ct);
+        if (atNode) trav_node_step<CNT, N64>(sc, nray, ntv, st, ct);
 #endif
       }
     }
@@ -817,8 +817,9 @@ size_t packetkernel_overflow_ints(int nBlocks, int ovfDepth) { return (size_t)nB
 
 template <bool CNT, bool FAST>
 static void launch_pk(dim3 grid, dim3 block, hipStream_t stream, const LaunchArgs& a) {
-  if (a.scene.shadowNearest) pt_packetkernel<CNT, true, FAST, true><<<grid, block, 0, stream>>>(a);
-  else                       pt_packetkernel<CNT, true, FAST, false><<<grid, block, 0, stream>>>(a);
+  const bool n64 = a.scene.nodes64 != nullptr;      // moptix_api.hip fill_view: the option node_format
+  if (a.scene.shadowNearest) { if (n64) pt_packetkernel<CNT, true, FAST, true, true><<<grid, block, 0, stream>>>(a); else pt_packetkernel<CNT, true, FAST, true, false><<<grid, block, 0, stream>>>(a); }
+  else                       { if (n64) pt_packetkernel<CNT, true, FAST, false, true><<<grid, block, 0, stream>>>(a); else pt_packetkernel<CNT, true, FAST, false, false><<<grid, block, 0, stream>>>(a); }
 }
 hipError_t launch_packetkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading) {
   dim3 grid(nBlocks), block(kBlockThreads);

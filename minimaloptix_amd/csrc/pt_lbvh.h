@@ -57,43 +57,42 @@ PT_HD float pad_hi(float v, float padAbs) { return v + (padAbs + 1e-6f * __built
 // Node128 -> Node64.  Every plane moves outwards to the node's 256-step grid, and by a margin of a few ulps more: the
 // kernels fold the decode into the slab test (t = fma(q, step/d, (corner - o)/d), pt_path.h), whose rounding differs from
 // fma(plane, 1/d, -o/d) by about an ulp of the larger coordinate, so the margin keeps the compressed test at least as
-// accepting as the uncompressed one.  Returns false if a grid step beyond 2^kNode64MaxExp would be needed (|1/d| is capped
-// at 1e30 by slab_inv; step/d has to stay finite): scenes wider than 255 * 2^26 units.
-constexpr int kNode64MaxExp = 26, kNode64MinExp = -100;
-PT_HD float node64_plane(float corner, int e, int q) { return fma_((float)q, __builtin_ldexpf(1.0f, e), corner); }
+// accepting as the uncompressed one.  Returns false if a step beyond kNode64MaxStep would be needed (|1/d| is capped at
+// 1e30 by slab_inv; step/d has to stay finite): scenes wider than 1e10 units.
+constexpr float kNode64MaxStep = 6.0e7f;
+PT_HD float node64_plane(float corner, float step, int q) { return fma_((float)q, step, corner); }
 PT_HD bool compress_node(const Node128& n, Node64& out) {
   const float lo[3][4] = { { n.lox.x, n.lox.y, n.lox.z, n.lox.w }, { n.loy.x, n.loy.y, n.loy.z, n.loy.w }, { n.loz.x, n.loz.y, n.loz.z, n.loz.w } };
   const float hi[3][4] = { { n.hix.x, n.hix.y, n.hix.z, n.hix.w }, { n.hiy.x, n.hiy.y, n.hiy.z, n.hiy.w }, { n.hiz.x, n.hiz.y, n.hiz.z, n.hiz.w } };
   bool ok = true;
-  float corner[3]; uint32_t exps = 0, ql[3] = { 0, 0, 0 }, qh[3] = { 0, 0, 0 };
+  float corner[3], step[3]; uint32_t ql[3] = { 0, 0, 0 }, qh[3] = { 0, 0, 0 };
   for (int a = 0; a < 3; a++) {
     float mn = 3.0e38f, mx = -3.0e38f;
     for (int k = 0; k < 4; k++) if (n.ref[k] != kEmptyRef) { mn = fminf_(mn, lo[a][k]); mx = fmaxf_(mx, hi[a][k]); }
     if (mn > mx) { mn = 0.f; mx = 0.f; }
     const float margin = 1e-6f * fmaxf_(__builtin_fabsf(mn), __builtin_fabsf(mx)) + 1e-30f;
     const float c = mn - margin, top = mx + margin;
-    int e = kNode64MinExp;
-    while (e < kNode64MaxExp && !(node64_plane(c, e, 255) >= top)) e++;
-    if (!(node64_plane(c, e, 255) >= top)) ok = false;
-    const float inv = __builtin_ldexpf(1.0f, -e);
+    float s = fmaxf_((top - c) * (1.0f / 255.0f), 1e-36f);
+    for (int it = 0; it < 64 && !(node64_plane(c, s, 255) >= top); it++) s = s * 1.0000002f + 1e-38f;      // a few ulps at most
+    if (!(node64_plane(c, s, 255) >= top) || !(s <= kNode64MaxStep)) ok = false;
+    const float inv = 1.0f / s;
     for (int k = 0; k < 4; k++) {
       int a0 = 255, a1 = 0;                 // an unused child: an inverted box (its ref says empty as well)
       if (n.ref[k] != kEmptyRef) {
         const float l = lo[a][k] - margin, h = hi[a][k] + margin;
         a0 = (int)fminf_(fmaxf_(__builtin_floorf((l - c) * inv), 0.f), 255.f);
-        while (a0 > 0 && node64_plane(c, e, a0) > l) a0--;
+        while (a0 > 0 && node64_plane(c, s, a0) > l) a0--;
         a1 = (int)fminf_(fmaxf_(__builtin_ceilf((h - c) * inv), 0.f), 255.f);
-        while (a1 < 255 && node64_plane(c, e, a1) < h) a1++;
+        while (a1 < 255 && node64_plane(c, s, a1) < h) a1++;
       }
       ql[a] |= (uint32_t)a0 << (8 * k); qh[a] |= (uint32_t)a1 << (8 * k);
     }
-    corner[a] = c; exps |= ((uint32_t)e & 0xffu) << (8 * a);
+    corner[a] = c; step[a] = s;
   }
   out.ox = corner[0]; out.oy = corner[1]; out.oz = corner[2];
-  out.exps = exps | ((uint32_t)n.count << 24);
+  out.sx = step[0]; out.sy = step[1]; out.sz = step[2];
   out.q[0] = ql[0]; out.q[1] = ql[1]; out.q[2] = ql[2]; out.q[3] = qh[0]; out.q[4] = qh[1]; out.q[5] = qh[2];
   for (int k = 0; k < 4; k++) out.ref[k] = n.ref[k];
-  out.pad[0] = 0; out.pad[1] = 0;
   return ok;
 }
 

@@ -61,15 +61,14 @@ static_assert(sizeof(Node128) == 128, "Node128 must be 128 bytes");
 
 // The same node in 64 bytes, the form the trace kernels fetch (PT_NODE64, pt_path.h): a lane's own node costs the L1 four
 // look-ups instead of seven, and the node array of a scene takes half the L2.  The children's boxes sit on a 256-step grid
-// laid over the node's own box: plane = corner + q * 2^e per axis, rounded OUTWARDS when the node is written
+// laid over the node's own box: plane = corner + q * step per axis, rounded OUTWARDS when the node is written
 // (pt_lbvh.h compress_node), so a quantised box contains the box it stands for and the traversal can only enter more
 // boxes, never fewer: which boxes are entered changes the amount of work, not a result (rule D5).
 struct alignas(64) Node64 {
   float ox, oy, oz;     // lower corner of the node's box (minus the margin compress_node adds)
-  uint32_t exps;        // bytes 0..2: e of axes x, y, z (signed); byte 3: children in use
+  float sx, sy, sz;     // grid step per axis: the smallest float with corner + 255 * step >= the upper corner
   uint32_t q[6];        // lox loy loz hix hiy hiz: byte k = child k, in grid steps from the corner
-  int ref[4];           // as Node128::ref
-  int pad[2];
+  int ref[4];           // as Node128::ref (unused children: kEmptyRef and an inverted box)
 };
 static_assert(sizeof(Node64) == 64, "Node64 must be 64 bytes");
 

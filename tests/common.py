@@ -80,7 +80,9 @@ HOSTSIM_COUNTERS = ("samples", "primaryRays", "bounceRays", "shadowRays", "nodeF
                     "lightLoads", "analyticTests")
 
 
-def hostsim_render(hs, seeds, leaf_size=4, accum=None):
+def hostsim_render(hs, seeds, leaf_size=4, accum=None, node_format=128):
+    """node_format 64: the CPU build walks the 64-byte nodes (pt_types.h Node64), as the packet kernel does by default."""
+    hostsim_lib().hostsim_set_node_format(int(node_format))
     s, keep = _hostsim_scene(hs)
     seeds = np.ascontiguousarray(np.asarray(seeds, np.int32))
     if accum is None:
@@ -89,6 +91,7 @@ def hostsim_render(hs, seeds, leaf_size=4, accum=None):
     timing = (C.c_double * 3)()
     rc = hostsim_lib().hostsim_render_timed(C.byref(s), leaf_size, seeds.ctypes.data_as(C.POINTER(C.c_int32)), len(seeds),
                                             accum.ctypes.data_as(C.POINTER(C.c_float)), cnt, timing)
+    hostsim_lib().hostsim_set_node_format(128)
     assert rc == 0
     out = dict(zip(HOSTSIM_COUNTERS, [int(x) for x in cnt]))
     out.update(build_s=timing[0], render_s=timing[1], threads=int(timing[2]))
@@ -96,16 +99,15 @@ def hostsim_render(hs, seeds, leaf_size=4, accum=None):
 
 
 def node64_boxes(n64):
-    """Decodes [n, 16]-word Node64 records as the kernels do (plane = fma(q, 2^e, corner), pt_lbvh.h node64_plane): returns
-    (boxes [n, 6, 4] float32 in the order lox loy loz hix hiy hiz x child, refs [n, 4] int32, count [n])."""
+    """Decodes [n, 16]-word Node64 records as the kernels do (plane = fma(q, step, corner), pt_lbvh.h node64_plane): returns
+    (boxes [n, 6, 4] float32 in the order lox loy loz hix hiy hiz x child, refs [n, 4] int32, steps [n, 3] float32)."""
     n64 = np.ascontiguousarray(n64, np.uint32)
     corner = n64[:, 0:3].view(np.float32).astype(np.float64)
-    e = ((n64[:, 3:4] >> (8 * np.arange(3, dtype=np.uint32))) & 0xff).astype(np.int8).astype(np.int32)
-    step = np.ldexp(1.0, e)
-    q = ((n64[:, 4:10, None] >> (8 * np.arange(4, dtype=np.uint32))) & 0xff).astype(np.float64)      # [n, 6, 4]
+    step = n64[:, 3:6].view(np.float32).astype(np.float64)
+    q = ((n64[:, 6:12, None] >> (8 * np.arange(4, dtype=np.uint32))) & 0xff).astype(np.float64)      # [n, 6, 4]
     ax = np.array([0, 1, 2, 0, 1, 2])
-    boxes = (q * step[:, ax, None] + corner[:, ax, None]).astype(np.float32)      # one rounding, as the fma
-    return boxes, n64[:, 10:14].view(np.int32), (n64[:, 3] >> 24).astype(np.int32)
+    boxes = (q * step[:, ax, None] + corner[:, ax, None]).astype(np.float32)      # exact product, one rounding: as the fma
+    return boxes, n64[:, 12:16].view(np.int32), n64[:, 3:6].view(np.float32)
 
 
 def hostsim_bvh(hs, leaf_size=4, builder=1, want_nodes64=False):

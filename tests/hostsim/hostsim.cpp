@@ -253,6 +253,8 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
     if (!compress_node(out.nodes[i], out.nodes64[i])) { fprintf(stderr, "[hostsim] node %zu is wider than the 64-byte form can hold\n", i); abort(); }
 }
 
+static int g_node64 = 0;        // hostsim_set_node_format: 1 = walk the 64-byte nodes, as the packet kernel does by default
+
 struct LocalStack {
   int data[256];
   inline void store(int sp, int v) { data[sp] = v; }
@@ -260,6 +262,10 @@ struct LocalStack {
   inline bool roomy(int) const { return true; }
   inline void store_fast(int sp, int v) { data[sp] = v; }
 };
+
+static inline void host_trav_step(const SceneView& sc, const PathState& ps, Trav& tv, LocalStack& st, Counters& ct) {
+  if (g_node64) trav_step<true, true>(sc, ps, tv, st, ct); else trav_step<true, false>(sc, ps, tv, st, ct);
+}
 
 struct HostScene {
   std::vector<DevMaterial> mats; std::vector<DevSphere> spheres; std::vector<int> sphereMat;
@@ -309,6 +315,7 @@ static void make_scene(const hostsim_scene& s, int leafSize, HostScene& hs) {
 extern "C" {
 
 void hostsim_set_builder(int builder) { g_builder = builder; }
+void hostsim_set_node_format(int bytes) { g_node64 = bytes == 64; }
 void hostsim_set_packet(int packet) { g_packet = packet; }
 
 int hostsim_build_bvh(const hostsim_scene* s, int leafSize, hostsim_bvh_out* out) {
@@ -359,18 +366,18 @@ int hostsim_render_timed(const hostsim_scene* s, int leafSize, const int32_t* se
             PathState r = ps; Trav ts; memset(&ts, 0, sizeof(ts));
             r.d = pk.sd[i]; r.tmin = sc.epsT; r.tmax = pk.stmax[i]; r.kind = RK_SHADOW;
             trav_begin<true>(sc, r, ts, ct);
-            while (ts.node != kTravDone) trav_step<true>(sc, r, ts, st, ct);
+            while (ts.node != kTravDone) host_trav_step(sc, r, ts, st, ct);
             att[i] = ts.att;
           }
           if (pk.hasBounce) {
             ps.kind = RK_RADIANCE;
             trav_begin<true>(sc, ps, tv, ct);
-            while (tv.node != kTravDone) trav_step<true>(sc, ps, tv, st, ct);
+            while (tv.node != kTravDone) host_trav_step(sc, ps, tv, st, ct);
           }
           ps.mode = M_RESULT;
         } else if (ps.mode == M_TRACE) {
           trav_begin<true>(sc, ps, tv, ct);
-          while (tv.node != kTravDone) trav_step<true>(sc, ps, tv, st, ct);
+          while (tv.node != kTravDone) host_trav_step(sc, ps, tv, st, ct);
           ps.mode = M_RESULT;
         } else if (ps.mode == M_RESULT && g_packet) {
           on_result_packet<true>(sc, ps, pk, tv, att, ct, PacketSink{ pk });

@@ -123,7 +123,7 @@ def test_device_lbvh_equals_host_mirror(gpu_ctx, leaf, builder):
     assert np.array_equal(prim, hp)
     assert np.array_equal(tris[:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]], ht[:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]])
     assert np.array_equal(nodes[:, :29], hn[:, :29])                     # boxes, refs and child count of every Node128
-    assert np.array_equal(n64[:, :14], h64[:, :14])                      # and of the 64-byte form the kernels fetch
+    assert np.array_equal(n64, h64)                      # and of the 64-byte form the kernels fetch
     gpu_ctx.set_option("leaf_size", 4)
 
 
@@ -378,3 +378,56 @@ def test_shadow_rays_through_glass_nearest_any_hit_surface_decides(gpu_ctx, tmp_
     o, ost = oracle_scene(hs).render(seeds)
     assert rmse(g / 6, o / 6) <= RMSE_TIGHT and st.rays == ost.rays and st.shadowRays == ost.shadowRays
     assert st.shadowRays > 0 and g.max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,kw", [("file:coffee", {}), ("coffee_pot_standin", {}), ("dining_standin", dict(iarg=2))])
+def test_node_format_changes_the_work_never_the_image(gpu_ctx, scene, kw):
+    """Option node_format (variant 4): the 64-byte nodes hold every child box rounded outwards on a 256-step grid, so the
+    kernel may enter more boxes than with the 128-byte nodes and must produce the same accumulator bits, the same rays and
+    the same hits; the automatic choice (0) settles on one of the two, the same one every time."""
+    hs = M.HostScene(scene, 160, 90, **kw)
+    seeds = M.launch_seeds(16)
+    res = {}
+    try:
+        gpu_ctx.set_option("kernel_variant", 4)
+        for fmt in (128, 64, 0, 0):
+            gpu_ctx.set_option("node_format", fmt)
+            gpu_ctx.load(hs); gpu_ctx.accum_clear()
+            st = gpu_ctx.render_counted(seeds)
+            assert gpu_ctx.get_option("kernel_variant_used") == 4
+            used = gpu_ctx.get_option("node_format_used")
+            assert used == (fmt or used) and used in (64, 128)
+            res.setdefault(fmt, []).append((gpu_ctx.accum_read(), st, used))
+    finally:
+        gpu_ctx.set_option("node_format", 0); gpu_ctx.set_option("kernel_variant", 3)
+    (a128, s128, _), (a64, s64, _) = res[128][0], res[64][0]
+    assert np.array_equal(a128.view(np.uint32), a64.view(np.uint32))
+    assert (s128.rays, s128.shadowRays, s128.closestHits) == (s64.rays, s64.shadowRays, s64.closestHits)
+    assert s128.nodeFetches <= s64.nodeFetches < 1.1 * s128.nodeFetches and s128.triTests <= s64.triTests < 1.35 * s128.triTests
+    (a0, s0, u0), (a1, s1, u1) = res[0]
+    assert u0 == u1 and np.array_equal(a0.view(np.uint32), a128.view(np.uint32))
+    assert s0.nodeFetches == (s64 if u0 == 64 else s128).nodeFetches
+    o, ost = oracle_scene(hs).render(seeds[:2]) if scene == "file:coffee" else (None, None)
+    if o is not None:
+        gpu_ctx.set_option("kernel_variant", 4); gpu_ctx.set_option("node_format", 64)
+        try:
+            gpu_ctx.load(hs); gpu_ctx.accum_clear(); st = gpu_ctx.render_counted(seeds[:2])
+            assert rmse(gpu_ctx.accum_read() / 2, o / 2) <= RMSE_TIGHT and st.rays == ost.rays
+        finally:
+            gpu_ctx.set_option("node_format", 0); gpu_ctx.set_option("kernel_variant", 3)
+
+
+@pytest.mark.gpu
+def test_node_format_verdicts_on_the_scenes_the_cost_model_was_fitted_to(gpu_ctx):
+    """coffee (curved mesh: +2 % work under the 64-byte nodes, 3 of 7 look-ups saved) takes them; the dining-room stand-in
+    (walls of two triangles each: every ray leaving a wall starts inside the wall's quantised box, +17 % triangle tests) keeps
+    the 128-byte nodes.  Full-size views, as profiles/r03_node_format.txt."""
+    try:
+        gpu_ctx.set_option("kernel_variant", 4); gpu_ctx.set_option("node_format", 0)
+        for scene, kw, want in (("file:coffee", {}, 64), ("dining_standin", dict(iarg=6), 128)):
+            hs = M.HostScene(scene, 1920, 1080, **kw)
+            gpu_ctx.load(hs); gpu_ctx.accum_clear(); gpu_ctx.render(M.launch_seeds(1))
+            assert gpu_ctx.get_option("node_format_used") == want, scene
+    finally:
+        gpu_ctx.set_option("kernel_variant", 3)
