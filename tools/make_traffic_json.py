@@ -25,7 +25,7 @@ kernels = set()
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r.get("Kernel_Name", "")
-        if not re.search(r"pt_(queue|packet)kernel<false, true(, false(, (false|true))?)?>", name):      # the exact-mode trace kernel only
+        if not re.search(r"pt_(queue|packet)kernel<false, true(, false(, (false|true)(, (false|true))?)?)?>", name):      # the exact-mode trace kernel only
             continue
         kernels.add(re.search(r"pt_\w+kernel<[^>]*>", name).group(0).replace(" ", ""))
         k = r.get("Counter_Name")
