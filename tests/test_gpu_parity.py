@@ -404,7 +404,7 @@ def test_node_format_changes_the_work_never_the_image(gpu_ctx, scene, kw):
     (a128, s128, _), (a64, s64, _) = res[128][0], res[64][0]
     assert np.array_equal(a128.view(np.uint32), a64.view(np.uint32))
     assert (s128.rays, s128.shadowRays, s128.closestHits) == (s64.rays, s64.shadowRays, s64.closestHits)
-    assert s128.nodeFetches <= s64.nodeFetches < 1.1 * s128.nodeFetches and s128.triTests <= s64.triTests < 1.35 * s128.triTests
+    assert s128.nodeFetches <= s64.nodeFetches < 1.35 * s128.nodeFetches and s128.triTests <= s64.triTests < 1.35 * s128.triTests
     (a0, s0, u0), (a1, s1, u1) = res[0]
     assert u0 == u1 and np.array_equal(a0.view(np.uint32), a128.view(np.uint32))
     assert s0.nodeFetches == (s64 if u0 == 64 else s128).nodeFetches

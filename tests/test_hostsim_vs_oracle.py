@@ -81,18 +81,21 @@ def test_compressed_nodes_contain_the_nodes_they_stand_for(scene, leaf):
     assert (qlo[~used] > qhi[~used]).all()
 
 
-def test_walking_the_compressed_nodes_gives_the_same_image_and_rays():
+@pytest.mark.parametrize("scene,kw", [("file:coffee", {}), ("dining_standin", dict(iarg=1)), ("million_standin", dict(iarg=20000)),
+                                      ("coffee_pot_standin", {})])
+def test_walking_the_compressed_nodes_gives_the_same_image_and_rays(scene, kw):
     """The node format changes which boxes are entered, never a result: same accumulator bits, same rays, same hits;
-    only the node / triangle test counts move (slightly up: the quantised boxes are a little larger)."""
-    hs = M.HostScene("file:coffee", 96, 54)
+    only the node / triangle test counts move (up: the quantised boxes are a little larger -- a lot more triangle tests only
+    where rays leave large flat faces, the dining room's walls)."""
+    hs = M.HostScene(scene, 96, 54, **kw)
     seeds = M.launch_seeds(2)
     a128, c128 = hostsim_render(hs, seeds, node_format=128)
     a64, c64 = hostsim_render(hs, seeds, node_format=64)
     assert np.array_equal(a128.view(np.uint32), a64.view(np.uint32))
     for k in ("samples", "primaryRays", "bounceRays", "shadowRays", "closestHits", "lightLoads"):
         assert c128[k] == c64[k], k
-    assert c128["nodeFetches"] <= c64["nodeFetches"] < 1.1 * c128["nodeFetches"]
-    assert c128["triTests"] <= c64["triTests"] < 1.1 * c128["triTests"]
+    assert c128["nodeFetches"] <= c64["nodeFetches"] < 1.35 * c128["nodeFetches"]
+    assert c128["triTests"] <= c64["triTests"] < 1.35 * c128["triTests"]
 
 
 def test_sah_topology_needs_fewer_node_fetches_and_gives_the_same_image():
