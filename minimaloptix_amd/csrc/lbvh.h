@@ -7,7 +7,7 @@ namespace pt {
 
 struct LbvhResult {
   Node128* nodes = nullptr;    // device, nNodes (four-wide)
-  Node64* nodes64 = nullptr;   // device, nNodes: the same nodes compressed (pt_lbvh.h compress_node); what the trace kernels fetch
+  Node64* nodes64 = nullptr;   // device, nNodes: the same nodes compressed (pt_lbvh.h compress_node), or nullptr if a node is too wide for the grid
   Tri48* tris = nullptr;       // device, nTris (sorted / leaf order)
   TriShade* shade = nullptr;   // device, nTris
   int nTris = 0, nNodes = 0, rootRef = kEmptyRef, depth = 0, leafSize = 0;   // depth: levels of four-wide nodes

@@ -635,7 +635,9 @@ hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dF
   LB_CHECK(hipEventRecord(e1, stream));
   LB_CHECK(hipStreamSynchronize(stream));
   LB_CHECK(hipGetLastError());
-  if (out->nNodes > 0 && pinned[4] != 0) { err = hipErrorInvalidValue; goto done; }     // a node wider than 1e10 units (pt_lbvh.h compress_node)
+  if (out->nNodes > 0 && pinned[4] != 0) {      // a node wider than 1e10 units (pt_lbvh.h compress_node): this tree has no 64-byte form
+    (void)hipFree(out->nodes64); out->nodes64 = nullptr;
+  }
   (void)hipEventElapsedTime(&out->buildMs, e0, e1);
   out->stackBound = wide_stack_bound(out->depth);
 

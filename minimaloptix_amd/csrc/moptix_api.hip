@@ -163,7 +163,7 @@ int choose_node_format(moptix_context c) {
   c->formatDecided = true;
   c->nodeFormatUsed = 128;
   for (auto& v : c->probeCounts) v = 0;
-  if (c->bvh.nNodes <= 0) return MOPTIX_OK;
+  if (c->bvh.nNodes <= 0 || !c->bvh.nodes64) return MOPTIX_OK;      // no tree, or one without a 64-byte form (lbvh.h)
   if (c->optNodeFormat != 0) { c->nodeFormatUsed = c->optNodeFormat; return MOPTIX_OK; }
   SceneView v; fill_view(c, v);
   v.nodes64 = c->bvh.nodes64;
@@ -705,7 +705,7 @@ int moptix_get_accel_info(moptix_context c, moptix_accel_info* out) {
   memset(out, 0, sizeof(*out));
   out->nTriangles = (uint32_t)c->bvh.nTris; out->nNodes = (uint32_t)c->bvh.nNodes; out->maxLeafSize = (uint32_t)c->bvh.leafSize;
   out->treeDepth = (uint32_t)c->bvh.depth; out->buildMs = c->bvh.buildMs;
-  out->nodeBytes = (uint64_t)c->bvh.nNodes * (sizeof(Node128) + sizeof(Node64)); out->triBytes = (uint64_t)c->bvh.nTris * sizeof(Tri48);
+  out->nodeBytes = (uint64_t)c->bvh.nNodes * (sizeof(Node128) + (c->bvh.nodes64 ? sizeof(Node64) : 0)); out->triBytes = (uint64_t)c->bvh.nTris * sizeof(Tri48);
   return MOPTIX_OK;
 }
 
@@ -870,6 +870,7 @@ int moptix_debug_read_nodes64(moptix_context c, void* nodes64) {
   if (!c || !nodes64) return MOPTIX_ERR_INVALID;
   if (!c->accelBuilt) return fail(c, MOPTIX_ERR_STATE, "no acceleration structure");
   HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
+  if (c->bvh.nNodes > 0 && !c->bvh.nodes64) return fail(c, MOPTIX_ERR_STATE, "this tree has no 64-byte form (a node is wider than 1e10 units)");
   if (c->bvh.nNodes > 0) HIPCHK(c, hipMemcpy(nodes64, c->bvh.nodes64, sizeof(Node64) * c->bvh.nNodes, hipMemcpyDeviceToHost), "read nodes64");
   return MOPTIX_OK;
 }

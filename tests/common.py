@@ -291,7 +291,7 @@ def textured_scene(root, width=96, height=72):
     return M.HostScene("file:cornell", width, height, base_folder=base)
 
 
-def write_glass_over_opaque_scene(root, glass_below):
+def write_glass_over_opaque_scene(root, glass_below, scale=1.0):
     """A floor (y = 0), a quad light above it (y = 3) and two large horizontal panes between them (y = 1.5 and 2), one Disney GLASS (tinted) and
     one opaque Disney, the glass one nearer to the floor when `glass_below`: every shadow ray from the floor to the light meets
     both.  disneyAnyHit accepts the glass hit without terminating the ray, so in OptiX the ray's interval ends there and the
@@ -302,7 +302,8 @@ def write_glass_over_opaque_scene(root, glass_below):
     def quad(name, y, hx, hz):
         with open(os.path.join(d, name), "w") as f:
             f.write("v %g %g %g\nv %g %g %g\nv %g %g %g\nv %g %g %g\nvn 0 1 0\nf 1//1 3//1 2//1\nf 1//1 4//1 3//1\n" % (
-                -hx, y, -hz, hx, y, -hz, hx, y, hz, -hx, y, hz))      # wound so that the geometric normal is +y
+                -hx * scale, y * scale, -hz * scale, hx * scale, y * scale, -hz * scale, hx * scale, y * scale, hz * scale,
+                -hx * scale, y * scale, hz * scale))      # wound so that the geometric normal is +y
     # scene box 0..2 in y: the cornell camera (MinimalOptiX.cpp:323-335) sits at its centre height 1, below both panes, and sees the floor
     quad("floor.obj", 0.0, 3.0, 1.5)
     quad("glass.obj", 1.5 if glass_below else 2.0, 3.0, 1.5)
@@ -340,12 +341,12 @@ mesh
 light
 {
     type Quad
-    position -1 3 -0.5
-    v1 1 3 -0.5
-    v2 -1 3 0.5
+    position %g %g %g
+    v1 %g %g %g
+    v2 %g %g %g
     emission 20 20 20
 }
-"""
+""" % tuple(scale * c for c in (-1, 3, -0.5, 1, 3, -0.5, -1, 3, 0.5))
     with open(os.path.join(d, "cornell.scene"), "w") as f:
         f.write(scene)
     return str(root) + "/"

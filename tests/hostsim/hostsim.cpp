@@ -250,7 +250,7 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   out.depth = subtree_depth(out.nodes, 0);
   out.nodes64.resize(out.nodes.size());
   for (size_t i = 0; i < out.nodes.size(); i++)
-    if (!compress_node(out.nodes[i], out.nodes64[i])) { fprintf(stderr, "[hostsim] node %zu is wider than the 64-byte form can hold\n", i); abort(); }
+    if (!compress_node(out.nodes[i], out.nodes64[i])) { out.nodes64.clear(); break; }      // too wide for the grid: no 64-byte form (as lbvh.hip)
 }
 
 static int g_node64 = 0;        // hostsim_set_node_format: 1 = walk the 64-byte nodes, as the packet kernel does by default
@@ -264,7 +264,7 @@ struct LocalStack {
 };
 
 static inline void host_trav_step(const SceneView& sc, const PathState& ps, Trav& tv, LocalStack& st, Counters& ct) {
-  if (g_node64) trav_step<true, true>(sc, ps, tv, st, ct); else trav_step<true, false>(sc, ps, tv, st, ct);
+  if (g_node64 && sc.nodes64) trav_step<true, true>(sc, ps, tv, st, ct); else trav_step<true, false>(sc, ps, tv, st, ct);
 }
 
 struct HostScene {
@@ -294,7 +294,7 @@ static void make_scene(const hostsim_scene& s, int leafSize, HostScene& hs) {
   for (int i = 0; i < s.nSpheres; i++) if (hs.mats[s.sphereMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
   for (int i = 0; i < s.nQuads; i++) if (hs.mats[s.quadMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
   v.nTris = s.nFaces; v.rootRef = hs.bvh.rootRef;
-  v.nodes = hs.bvh.nodes.data(); v.nodes64 = hs.bvh.nodes64.data(); v.tris = hs.bvh.tris.data(); v.triShade = hs.bvh.shade.data();
+  v.nodes = hs.bvh.nodes.data(); v.nodes64 = hs.bvh.nodes64.empty() ? nullptr : hs.bvh.nodes64.data(); v.tris = hs.bvh.tris.data(); v.triShade = hs.bvh.shade.data();
   bool anyUV = false;
   for (int f = 0; f < s.nFaces; f++) {
     TriUV uv; memset(&uv, 0, sizeof(uv));

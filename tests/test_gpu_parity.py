@@ -431,3 +431,25 @@ def test_node_format_verdicts_on_the_scenes_the_cost_model_was_fitted_to(gpu_ctx
             assert gpu_ctx.get_option("node_format_used") == want, scene
     finally:
         gpu_ctx.set_option("kernel_variant", 3)
+
+
+@pytest.mark.gpu
+def test_a_tree_too_wide_for_the_node_grid_keeps_the_128_byte_nodes(gpu_ctx, tmp_path):
+    """compress_node gives up on a node wider than 255 grid steps of 6e7 units (step/d has to stay finite for |1/d| up to 1e30):
+    such a tree has no 64-byte form, the packet kernel walks the 128-byte nodes whatever node_format says, and the image is the
+    per-lane kernel's."""
+    from common import write_glass_over_opaque_scene
+    hs = M.HostScene("file:cornell", 64, 48, base_folder=write_glass_over_opaque_scene(tmp_path, True, scale=1e10))
+    seeds = M.launch_seeds(4)
+    try:
+        gpu_ctx.set_option("kernel_variant", 4); gpu_ctx.set_option("node_format", 64)
+        gpu_ctx.load(hs); gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+        assert gpu_ctx.accel_info().nNodes > 0 and gpu_ctx.get_option("node_format_used") == 128
+        with pytest.raises(M.MoptixError):
+            gpu_ctx.debug_read_nodes64()
+        g4 = gpu_ctx.accum_read()
+        gpu_ctx.set_option("kernel_variant", 0)
+        gpu_ctx.accum_clear(); gpu_ctx.render(seeds)
+        assert np.array_equal(g4.view(np.uint32), gpu_ctx.accum_read().view(np.uint32))
+    finally:
+        gpu_ctx.set_option("node_format", 0); gpu_ctx.set_option("kernel_variant", 3)

@@ -98,6 +98,19 @@ def test_walking_the_compressed_nodes_gives_the_same_image_and_rays(scene, kw):
     assert c128["triTests"] <= c64["triTests"] < 1.35 * c128["triTests"]
 
 
+def test_a_tree_too_wide_for_the_node_grid_has_no_compressed_form(tmp_path):
+    from common import write_glass_over_opaque_scene
+    hs = M.HostScene("file:cornell", 32, 24, base_folder=write_glass_over_opaque_scene(tmp_path, True, scale=1e10))
+    nodes, tris, prim, root, depth, n64 = hostsim_bvh(hs, 4, 1, want_nodes64=True)
+    assert len(nodes) > 0 and not n64.any()                              # nothing was written
+    hs = M.HostScene("file:cornell", 32, 24, base_folder=write_glass_over_opaque_scene(tmp_path, True, scale=1e3))
+    nodes, tris, prim, root, depth, n64 = hostsim_bvh(hs, 4, 1, want_nodes64=True)
+    assert len(nodes) > 0 and n64.any()
+    a128, _ = hostsim_render(hs, M.launch_seeds(2), node_format=128)
+    a64, _ = hostsim_render(hs, M.launch_seeds(2), node_format=64)
+    assert np.array_equal(a128.view(np.uint32), a64.view(np.uint32))
+
+
 def test_sah_topology_needs_fewer_node_fetches_and_gives_the_same_image():
     """The binned-SAH topology (what the reference gets from "Trbvh") against the plain Morton radix tree: same bits
     (the hit is independent of the tree), at least 15 % fewer four-wide node fetches per ray on the coffee scene."""
