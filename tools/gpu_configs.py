@@ -14,10 +14,11 @@ def timing(kind, kw, res, spp):
     hs = M.HostScene(kind, res[0], res[1], **kw); seeds = M.launch_seeds(spp)
     ctx.load(hs); a = ctx.accel_info()
     ctx.accum_clear(); st = ctx.render_counted(seeds)
-    B = 64 * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * res[0] * res[1]
+    nb = ctx.get_option("node_format_used") if ctx.get_option("kernel_variant_used") == 4 else 128      # the node record that launch fetched
+    B = nb * st.nodeFetches + 48 * st.triTests + 108 * st.closestHits + 72 * st.lightLoads + 24 * res[0] * res[1]
     ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); ms, n = ctx.kernel_time()
-    print("TIMING %-16s %dx%d spp %d: %.1f ms (%d launches) %.1f Mrays/s rays/sample %.2f  alg %.2f TB/s  analytic tests/s %.3g | tris %d nodes %d depth %d build %.2f ms" % (
-        kind, res[0], res[1], spp, ms, n, st.rays / ms / 1e3, st.rays / st.samples, B / ms / 1e9, st.analyticTests / ms * 1e3, a.nTriangles, a.nNodes, a.treeDepth, a.buildMs), flush=True)
+    print("TIMING %-16s %dx%d spp %d: %.1f ms (%d launches) %.1f Mrays/s rays/sample %.2f  alg %.2f TB/s  analytic tests/s %.3g | tris %d nodes %d (%d B) depth %d build %.2f ms" % (
+        kind, res[0], res[1], spp, ms, n, st.rays / ms / 1e3, st.rays / st.samples, B / ms / 1e9, st.analyticTests / ms * 1e3, a.nTriangles, a.nNodes, nb, a.treeDepth, a.buildMs), flush=True)
     if a.nTriangles == 0:
         # scenes without an acceleration structure are FP32-VALU bound -- flops, not bytes.  Per primitive test: sphere
         # 17 flop (oc 3, b = d.oc 5, c = oc.oc - r^2 7, disc 2; the roots only where disc >= 0 are not counted), quad 20 flop
