@@ -1,6 +1,8 @@
 """The megakernel's per-lane code compiled for the host (tests/hostsim) against the recursive CPU
 oracle: same paths, same ray counts.  This is what is checked before any GPU time is spent; the
 GPU tests then check that the device runs the same code to the same bits."""
+import os
+
 import numpy as np
 import pytest
 
@@ -133,3 +135,53 @@ def test_leaf_size_does_not_change_the_image():
     a, _ = hostsim_render(hs, seeds, leaf_size=1)
     b, _ = hostsim_render(hs, seeds, leaf_size=8)
     assert np.array_equal(a, b)        # equal-t rule makes the hit independent of the tree
+
+
+def _write_soup_scene(root, rng, n, scale, offset):
+    """n random triangles in a unit cube (some tiny, some spanning it, some axis-aligned flats), scaled and shifted, a floor
+    under them and a quad light above: a stress scene for the node compression (large |coordinate| / extent ratios)."""
+    d = os.path.join(str(root), "cornell")
+    os.makedirs(d, exist_ok=True)
+    c = rng.random((n, 1, 3)); size = 10.0 ** rng.uniform(-3, 0, (n, 1, 1))
+    v = c + (rng.random((n, 3, 3)) - 0.5) * size
+    flat = rng.random(n) < 0.2
+    v[flat, :, rng.integers(0, 3)] = c[flat, :, 0][:, :1]          # a fifth of them flat on one axis
+    v = v * scale + offset
+    with open(os.path.join(d, "soup.obj"), "w") as f:
+        for t in v:
+            for p in t:
+                f.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for i in range(n):
+            f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    lo, hi = np.array([-0.5, -0.05, -0.5]) * scale + offset, np.array([1.5, -0.05, 1.5]) * scale + offset
+    with open(os.path.join(d, "floor.obj"), "w") as f:
+        f.write("v %.9g %.9g %.9g\nv %.9g %.9g %.9g\nv %.9g %.9g %.9g\nv %.9g %.9g %.9g\nf 1 3 2\nf 1 4 3\n" % (
+            lo[0], lo[1], lo[2], hi[0], lo[1], lo[2], hi[0], lo[1], hi[2], lo[0], lo[1], hi[2]))
+    L = np.array([[0.2, 1.6, 0.2], [0.8, 1.6, 0.2], [0.2, 1.6, 0.8]]) * scale + offset
+    with open(os.path.join(d, "cornell.scene"), "w") as f:
+        f.write("material Grey\n{\n    color 0.7 0.7 0.7\n    roughness 0.5\n}\nmaterial Shiny\n{\n    color 0.8 0.5 0.3\n    roughness 0.1\n    metallic 0.5\n}\n"
+                "mesh\n{\n    file floor.obj\n    material Grey\n}\nmesh\n{\n    file soup.obj\n    material Shiny\n}\n"
+                "light\n{\n    type Quad\n    position %.9g %.9g %.9g\n    v1 %.9g %.9g %.9g\n    v2 %.9g %.9g %.9g\n    emission 15 15 15\n}\n" % tuple(L.ravel()))
+    return str(root) + "/"
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1e-3, 0.0), (1e4, 0.0), (1.0, 1e4), (10.0, -3e5)])
+def test_compressed_nodes_on_random_triangle_soups(tmp_path, scale, offset):
+    """Containment and image equality of the two node formats where the grid is stressed: tiny and huge scenes, scenes far from
+    the origin (few mantissa bits left inside the node), flat and needle triangles."""
+    import os  # noqa: F401
+    rng = np.random.default_rng(int(abs(scale) * 1000 + abs(offset)) % (2 ** 31))
+    hs = M.HostScene("file:cornell", 48, 36, base_folder=_write_soup_scene(tmp_path, rng, 700, scale, offset))
+    nodes, tris, prim, root, depth, n64 = hostsim_bvh(hs, 4, 1, want_nodes64=True)
+    assert len(nodes) > 100 and n64.any()
+    boxes = nodes[:, :24].view(np.float32).reshape(len(nodes), 6, 4)
+    refs = nodes[:, 24:28].view(np.int32)
+    qb, qrefs, step = node64_boxes(n64)
+    used = (refs != 0x7ffffffe)[:, None, :].repeat(3, axis=1)
+    assert np.array_equal(qrefs, refs)
+    assert (qb[:, 0:3][used] <= boxes[:, 0:3][used]).all() and (qb[:, 3:6][used] >= boxes[:, 3:6][used]).all()
+    seeds = M.launch_seeds(3)
+    a128, c128 = hostsim_render(hs, seeds, node_format=128)
+    a64, c64 = hostsim_render(hs, seeds, node_format=64)
+    assert np.array_equal(a128.view(np.uint32), a64.view(np.uint32)) and a128.max() > 0
+    assert (c128["bounceRays"], c128["shadowRays"], c128["closestHits"]) == (c64["bounceRays"], c64["shadowRays"], c64["closestHits"])
