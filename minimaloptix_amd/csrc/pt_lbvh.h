@@ -77,7 +77,7 @@ PT_HD bool compress_node(const Node128& n, Node64& out) {
     if (!(node64_plane(c, s, 255) >= top) || !(s <= kNode64MaxStep)) ok = false;
     const float inv = 1.0f / s;
     for (int k = 0; k < 4; k++) {
-      int a0 = 255, a1 = 0;                 // an unused child: an inverted box (its ref says empty as well)
+      int a0 = 255, a1 = 0;                 // an unused child is skipped by its ref (kEmptyRef); its bytes only mark it for readers of the array
       if (n.ref[k] != kEmptyRef) {
         const float l = lo[a][k] - margin, h = hi[a][k] + margin;
         a0 = (int)fminf_(fmaxf_(__builtin_floorf((l - c) * inv), 0.f), 255.f);

@@ -68,7 +68,7 @@ struct alignas(64) Node64 {
   float ox, oy, oz;     // lower corner of the node's box (minus the margin compress_node adds)
   float sx, sy, sz;     // grid step per axis: the smallest float with corner + 255 * step >= the upper corner
   uint32_t q[6];        // lox loy loz hix hiy hiz: byte k = child k, in grid steps from the corner
-  int ref[4];           // as Node128::ref (unused children: kEmptyRef and an inverted box)
+  int ref[4];           // as Node128::ref (unused children: kEmptyRef; their plane bytes are 255 / 0)
 };
 static_assert(sizeof(Node64) == 64, "Node64 must be 64 bytes");
 
