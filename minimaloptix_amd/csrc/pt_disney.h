@@ -87,28 +87,32 @@ PT_HD v3 cosine_sample_hemisphere(float u1, float u2) {
 }
 
 // disney.h:9-30
-// onb = make_onb(N): disney.h builds it in disneySample and again in disneyEval; the caller builds it once
+// onb = make_onb(N): disney.h builds it in disneySample and again in disneyEval; the caller builds it once.
+//
+// The two lobes are written as ONE instruction stream with selects: a wave whose lanes chose different lobes would otherwise run
+// both branches one after the other (two sincos, four square roots, four normalisations: ~350 vector instructions against ~250
+// here).  Every lane performs exactly the operations of its own branch of disney.h on exactly its operands, in the same order
+// -- the other lobe's values are computed beside them and dropped --, so L and H are the same bits as before:
+//   diffuse (disney.h:12-18)   u1 = ra, u2 = rb: cosine_sample_hemisphere -> r = sqrt(u1), phi = (2 pi) u2,
+//                              p = (r cos phi, r sin phi, sqrt(max(0, 1 - px px - py py))); L = normalize(onb p); H = normalize(L + V)
+//   specular (disney.h:20-29)  phi = ra * 2 * pi, random = rb: cosTheta = sqrt((1 - random) / (1 + (a a - 1) random)),
+//                              sinTheta = sqrt(1 - cosTheta cosTheta), h = onb (sinTheta cos phi, sinTheta sin phi, cosTheta);
+//                              L = normalize(h * (2 dot(V, h)) - V); H = normalize(h)
 PT_HD_BRDF void disney_sample(uint32_t& seed, const DevMaterial& m, const Onb& onb, v3 V, v3& L, v3& H) {
   typedef ShadeMath<false> SM;         // directions are part of the path: always exact
-  if (rnd(seed) < m.diffuseRatio) {
-    float u1 = rnd(seed); float u2 = rnd(seed);
-    v3 l = cosine_sample_hemisphere(u1, u2);
-    l = onb_inverse(onb, l);
-    L = SM::normalize(l);
-    H = SM::normalize(L + V);
-  } else {
-    float a = m.specAlpha;
-    float phi = rnd(seed) * 2.0f * kPi;
-    float random = rnd(seed);
-    float cosTheta = SM::sqrt(SM::div(1.f - random, 1.0f + (a * a - 1.f) * random));
-    float sinTheta = SM::sqrt(1.0f - (cosTheta * cosTheta));
-    float sinPhi, cosPhi;
-    sincos_ac(phi, sinPhi, cosPhi);
-    v3 h = mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
-    h = onb_inverse(onb, h);
-    L = SM::normalize(h * (2.0f * dot(V, h)) - V);
-    H = SM::normalize(h);
-  }
+  const bool diffuse = rnd(seed) < m.diffuseRatio;
+  const float ra = rnd(seed), rb = rnd(seed);
+  const float phi = diffuse ? (2.0f * kPi) * rb : ra * 2.0f * kPi;
+  float sinPhi, cosPhi;
+  sincos_ac(phi, sinPhi, cosPhi);
+  const float a = m.specAlpha;
+  const float s1 = SM::sqrt(diffuse ? ra : SM::div(1.f - rb, 1.0f + (a * a - 1.f) * rb));      // r | cosTheta
+  const float px = s1 * cosPhi, py = s1 * sinPhi;                                               // the diffuse lobe's p.x, p.y
+  const float s2 = SM::sqrt(diffuse ? fmaxf_(0.0f, 1.0f - px * px - py * py) : 1.0f - (s1 * s1));   // p.z | sinTheta
+  const v3 local = diffuse ? mk3(px, py, s2) : mk3(s2 * cosPhi, s2 * sinPhi, s1);
+  const v3 w = onb_inverse(onb, local);                                                          // l | h
+  L = SM::normalize(diffuse ? w : w * (2.0f * dot(V, w)) - V);
+  H = SM::normalize(diffuse ? L + V : w);
 }
 
 // disney.h:32-46
