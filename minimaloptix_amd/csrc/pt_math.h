@@ -103,6 +103,11 @@ PT_HD float i2f(int32_t i) { return __builtin_bit_cast(float, i); }
 constexpr float kPi = 3.14159265358979323846f;   // M_PIf
 constexpr float kRtDefaultMax = 1e27f;           // RT_DEFAULT_MAX
 
+// length(a) != 0 without the square root: sqrtf(x) is zero exactly when x is (and NaN for NaN, which compares unequal to zero
+// either way), so the decision is the one `length(a) != 0.0f` makes (Material.cu:197) -- a correctly rounded square root is
+// ~19 vector instructions here.
+PT_HD bool length_is_nonzero(v3 a) { return dot(a, a) != 0.0f; }
+
 // optixu reflect / faceforward / refract
 PT_HD v3 reflect(v3 i, v3 n) { return i - (n * 2.0f) * dot(n, i); }
 PT_HD v3 faceforward(v3 n, v3 i, v3 nref) { return n * __builtin_copysignf(1.0f, dot(i, nref)); }

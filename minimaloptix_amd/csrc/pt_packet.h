@@ -119,7 +119,7 @@ PT_HD void on_result_packet(const SceneView& sc, PathState& ps, Packet& pk, cons
 #pragma unroll
 #endif
   for (int i = 0; i < kPacketShadows; i++) {                      // Material.cu:193-201, light order
-    if (i < pk.nShadow && pk.pendInv[i] != 0.f && length(att[i]) != 0.0f) {
+    if (i < pk.nShadow && pk.pendInv[i] != 0.f && length_is_nonzero(att[i])) {
       const v3 c = (pk.pendW[i] * att[i]) * pk.pendInv[i];
       ps.rad = ps.rad + ps.thr * c;
     }

@@ -543,7 +543,7 @@ PT_HD void hit_attributes(const SceneView& sc, const PathState& ps, const Trav& 
 template <bool CNT>
 PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counters& ct) {
   if (ps.kind == RK_SHADOW) {                                   // Material.cu:193-201
-    if (ps.pendInv != 0.f && length(tv.att) != 0.0f) {
+    if (ps.pendInv != 0.f && length_is_nonzero(tv.att)) {
       const v3 c = (ps.pendW * tv.att) * ps.pendInv;
       ps.rad = ps.rad + ps.thr * c;
     }
