@@ -446,14 +446,21 @@ struct RcclApi {
   decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr;
   bool ok = false; std::string error;
 };
-RcclApi& rccl() {
-  static RcclApi api;
-  static bool tried = false;
-  if (tried) return api;
-  tried = true;
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) { api.error = std::string("cannot load librccl: ") + dlerror(); return api; }
+// MOPTIX_RCCL_LIB names another library with the same nine entry points (a transport plug point; tests/rccl_loopback is a
+// loop-back transport that lets the N > 1 branches below run as N processes on a ONE-GPU box, where RCCL itself refuses a
+// communicator whose ranks share a device).  Loaded once; the C++11 static makes the first call thread-safe.
+RcclApi load_rccl() {
+  RcclApi api;
+  const char* override_ = getenv("MOPTIX_RCCL_LIB");
+  void* h = nullptr;
+  if (override_ && *override_) {
+    h = dlopen(override_, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { api.error = std::string("cannot load MOPTIX_RCCL_LIB: ") + dlerror(); return api; }
+  } else {
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { api.error = std::string("cannot load librccl: ") + dlerror(); return api; }
+  }
   bool all = true;
   auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) { all = false; api.error = std::string("librccl lacks ") + n; } return p; };
   api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId"); api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
@@ -461,6 +468,10 @@ RcclApi& rccl() {
   api.Send = (decltype(api.Send))sym("ncclSend"); api.Recv = (decltype(api.Recv))sym("ncclRecv"); api.Reduce = (decltype(api.Reduce))sym("ncclReduce");
   api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart"); api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
   api.ok = all;
+  return api;
+}
+RcclApi& rccl() {
+  static RcclApi api = load_rccl();
   return api;
 }
 int ncclFail(moptix_context c, ncclResult_t r, const char* what) {
@@ -1003,9 +1014,12 @@ int moptix_gather_tiles(moptix_context c, int32_t dstRank) {
   } else {
     HIPCHK(c, c->dTileRecv.ensure(cnt * (size_t)n), "alloc tile staging");
     NCCLCHK(c, rccl().GroupStart(), "ncclGroupStart");
-    for (int r = 0; r < n; r++)
-      if (r != dstRank) NCCLCHK(c, rccl().Recv(c->dTileRecv.p + cnt * (size_t)r, cnt, ncclFloat, r, c->comm, c->stream), "ncclRecv");
-    NCCLCHK(c, rccl().GroupEnd(), "ncclGroupEnd");
+    ncclResult_t recvErr = ncclSuccess;
+    for (int r = 0; r < n && recvErr == ncclSuccess; r++)
+      if (r != dstRank) recvErr = rccl().Recv(c->dTileRecv.p + cnt * (size_t)r, cnt, ncclFloat, r, c->comm, c->stream);
+    const ncclResult_t endErr = rccl().GroupEnd();           // always: a group left open would swallow every later call of this thread
+    if (recvErr != ncclSuccess) return ncclFail(c, recvErr, "ncclRecv");
+    if (endErr != ncclSuccess) return ncclFail(c, endErr, "ncclGroupEnd");
     for (int r = 0; r < n; r++) {                            // the other ranks' tiles into this rank's accuBuffer
       if (r == dstRank) continue;
       TileDeal dr = d; dr.rank = r;

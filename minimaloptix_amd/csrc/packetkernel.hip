@@ -37,9 +37,6 @@ constexpr int kWaves = kBlockThreads / 64;
 #ifndef PT_STACKN
 #define PT_STACKN 11
 #endif
-#ifndef PT_QUAD_FETCH
-#define PT_QUAD_FETCH 0      // 1 = node loop: the four lanes of a quad fetch their nodes together (pt_path.h trav_node_step_quad); measured 508 ms against 440 ms per frame
-#endif
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 3
 #endif
@@ -185,6 +182,21 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
   return v;
+}
+
+// The launch arguments again, read from the kernel-argument segment through a pointer the compiler cannot see through.
+// The kernel is one loop; whatever it reads from its arguments is loop-invariant, so the compiler loads ALL of it in front
+// of the loop and keeps it in scalar registers for the whole launch: camera (19 words), background, a dozen table pointers,
+// the hand-out parameters -- about 100 words against 102 registers, and the rest of the kernel's scalar state (queue heads,
+// exec masks of the scheduler) then lives in lanes of a spill VGPR, one v_readlane / v_writelane (4.4 clocks of the vector
+// pipe each, tools/micro/valu_issue.hip) per access: 111 spilled scalar registers in round 3.  A pass that needs the scene
+// (shading batch, leaf pass) therefore takes its own copy here: s_load where the value is used, dead when the pass ends,
+// and only what the node loop and the scheduler need stays resident.
+__device__ __forceinline__ const LaunchArgs& fresh_args() {
+  typedef __attribute__((address_space(4))) const LaunchArgs CA;
+  unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const LaunchArgs*)(CA*)p;
 }
 
 // destination queue of a slot after a traversal step / a ray set-up
@@ -396,6 +408,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
 
   // ---- leaf pass: the slots popped from Q_LEAF stand at a leaf ----
   auto leaf_pass = [&](int slot) {
+    const LaunchArgs& a = fresh_args();                 // this pass's own view of the arguments (see fresh_args)
+    SceneView scl = a.scene; scl.shadowNearest = NEAR ? 1 : 0;
+    const SceneView& sc = scl;
     const bool have = slot >= 0;
     if (CNT) { leafPasses++; leafLanes += (uint32_t)__popcll(__ballot(have)); }
     pendSlot = slot; pendDest = DEST_NONE;
@@ -489,6 +504,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
 
   // ---- shading / regeneration batch: run the path state machine for the popped slots ----
   auto run_batch = [&](int slot, bool shadeBatch) {
+    const LaunchArgs& a = fresh_args();                 // this pass's own view of the arguments (see fresh_args)
+    SceneView scl = a.scene; scl.shadowNearest = NEAR ? 1 : 0;
+    const SceneView& sc = scl;
     const bool have = slot >= 0;
     if (CNT) { batches++; batchLanes += (uint32_t)__popcll(__ballot(have)); }
     PT_SUB0();
@@ -771,11 +789,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         const int n = __popcll(m);
         if (n == 0 || nActive - n >= a.swapLanes) break;
         if (CNT) { nodeSteps++; nodeLanes += (uint32_t)n; }
-#if PT_QUAD_FETCH
-        trav_node_step_quad<CNT>(sc, nray, ntv, st, ct, atNode);
-#else
         if (atNode) trav_node_step<CNT, N64>(sc, nray, ntv, st, ct);
-#endif
       }
     }
     PT_STAMP(tNode);

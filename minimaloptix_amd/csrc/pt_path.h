@@ -78,12 +78,11 @@ PT_HD bool shadow_any_hit(const SceneView& sc, int mat, v3& att) {
   return true;                                            // rtTerminateRay
 }
 PT_HD void shadow_candidate(const SceneView& sc, int mat, float t, int prim, float tmin, float& tbest, int& bestPrim, v3& att) {
+  if (!potential(t, prim, tmin, tbest, bestPrim)) return;      // most candidates are not nearer: no material fetch for them
   const DevMaterial m = load_const(sc.mats + mat);
   if (m.kind != MAT_DISNEY) return;
-  if (potential(t, prim, tmin, tbest, bestPrim)) {
-    tbest = t; bestPrim = prim;
-    att = (m.brdfType == BRDF_GLASS) ? m.color : mk3(0.f, 0.f, 0.f);
-  }
+  tbest = t; bestPrim = prim;
+  att = (m.brdfType == BRDF_GLASS) ? m.color : mk3(0.f, 0.f, 0.f);
 }
 
 // 1/d for the slab planes.  A direction component below 1e-30 in magnitude is treated as +-1e-30 so that
@@ -191,177 +190,129 @@ PT_HD void trav_pop(Trav& tv, Stack& st) {
   else { tv.sp--; tv.node = st.load(tv.sp); }
 }
 
-// One four-child node (one 128-byte line) for a lane with tv.node >= 0: the children the ray enters are
-// visited nearest first (a 5-exchange sorting network on (entry distance, ref)); the order affects only the
-// amount of work, never the result (equal-t rule D5 is order independent).
+// One four-child node for a lane with tv.node >= 0: the children the ray enters are visited nearest first; the order
+// affects only the amount of work, never the result (equal-t rule D5 is order independent).
 //
-// Slab planes are evaluated as t = fma(plane, 1/d, -(o/d)): one instruction per plane.  Compared with (plane - o) * (1/d) the rounding error moves by about one ulp of o
-// in space, far inside the padding of the boxes (pt_lbvh.h pad_lo/pad_hi); 1/d is kept finite (slab_inv).  The test stays conservative, and nothing
-// downstream depends on which boxes were entered.
-PT_HD void sort2(float& ta, int& ra, float& tb, int& rb) {
-  const bool sw = tb < ta;
-  const float t0 = sw ? tb : ta, t1 = sw ? ta : tb;
-  const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
-  ta = t0; tb = t1; ra = r0; rb = r1;
-}
-// PT_PK_SLAB=1 evaluates two planes per v_pk_fma_f32.  Measured on coffee: 3 % slower than the scalar fma form
-// (the node loop waits for memory, not for the VALU), so it is off.
-#ifndef PT_PK_SLAB
-#define PT_PK_SLAB 0
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && PT_PK_SLAB
-typedef float pt_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void planes4(const v4& p, float inv, float noi, float out[4]) {
-  const pt_f2 i2 = { inv, inv }, n2 = { noi, noi };
-  const pt_f2 a = __builtin_elementwise_fma(pt_f2{ p.x, p.y }, i2, n2), b = __builtin_elementwise_fma(pt_f2{ p.z, p.w }, i2, n2);
-  out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y;
-}
+// Slab planes are evaluated as t = fma(plane, 1/d, -(o/d)): one instruction per plane.  Compared with (plane - o) * (1/d) the
+// rounding error moves by about one ulp of o in space, far inside the padding of the boxes (pt_lbvh.h pad_lo/pad_hi); 1/d is
+// kept finite (slab_inv).  The test stays conservative, and nothing downstream depends on which boxes were entered.
+//
+// What the node step costs is set by WHICH vector instructions it issues (tools/micro/valu_issue.hip,
+// profiles/r04_valu_ceiling.txt): on gfx950 v_fma / v_mul / v_add / v_mov / v_and / v_or / v_lshrrev issue at ~2.35 clocks per
+// wave64 instruction per SIMD, everything else this code needs -- v_min / v_max / v_max3, v_cvt_f32_ubyteN, v_cmp, v_cndmask,
+// the f64 min / max -- at ~4.3.  Hence
+//   * near / far plane per axis by the SIGN of the ray's direction, chosen on the packed plane words of the 64-byte node
+//     before they are unpacked (6 selects per node) instead of ordering each pair of plane distances (24 min / max);
+//   * the entered children are sorted as 64-bit keys (entry distance's bits in the high word, child reference in the low
+//     word) with v_min_f64 / v_max_f64: 10 instructions for the 5-exchange network instead of 5 compares + 20 selects -- a
+//     positive float's bits order like the float, and a double whose high word they are orders like its high word;
+//   * children 0 and 1 of a node always exist (pt_lbvh.h emits 2..4 children, unused slots last): two empty tests, not four.
+struct ChildKey {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double v;
+  PT_HD static ChildKey make(float t, int ref) {
+    ChildKey k; k.v = __builtin_bit_cast(double, ((unsigned long long)(uint32_t)f2i(t) << 32) | (uint32_t)ref); return k;
+  }
+  PT_HD float t() const { return i2f((int32_t)(__builtin_bit_cast(unsigned long long, v) >> 32)); }
+  PT_HD int ref() const { return (int32_t)(uint32_t)__builtin_bit_cast(unsigned long long, v); }
+  // inline assembly: llvm.minnum on a value that came out of a bit cast gets a canonicalising v_max_f64 x, x in front
+  PT_HD static void order(ChildKey& a, ChildKey& b) {
+    double lo, hi;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a.v), "v"(b.v));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a.v), "v"(b.v));
+    a.v = lo; b.v = hi;
+  }
 #else
-PT_HD void planes4(const v4& p, float inv, float noi, float out[4]) {
-  out[0] = fma_(p.x, inv, noi); out[1] = fma_(p.y, inv, noi); out[2] = fma_(p.z, inv, noi); out[3] = fma_(p.w, inv, noi);
-}
+  unsigned long long v;      // same order: the keys are positive normal doubles (t >= tmin > 0, below the NaN patterns)
+  PT_HD static ChildKey make(float t, int ref) { ChildKey k; k.v = ((unsigned long long)(uint32_t)f2i(t) << 32) | (uint32_t)ref; return k; }
+  PT_HD float t() const { return i2f((int32_t)(v >> 32)); }
+  PT_HD int ref() const { return (int32_t)(uint32_t)v; }
+  PT_HD static void order(ChildKey& a, ChildKey& b) { if (b.v < a.v) { const unsigned long long x = a.v; a.v = b.v; b.v = x; } }
 #endif
+};
 #ifndef PT_STACK_ROOMY
 #define PT_STACK_ROOMY 1
 #endif
-// The slab tests, the sort and the pushes of one four-child node whose record is already in registers.
-// The sort and the pushes of one four-child node whose twenty-four plane distances are known.
+// The slab tests, the sort and the pushes of one four-child node whose plane distances are known: tnr / tfr = distance to
+// the plane of child k's box the ray meets first / last, per axis.  needTest[k]: child k may be an unused slot.
 template <bool CNT, class Stack>
-PT_HD void node_step_planes(const PathState& ps, Trav& tv, Stack& st, Counters& ct, const float ax[4], const float bx[4], const float ay[4],
-                            const float by[4], const float az[4], const float bz[4], int r0, int r1, int r2, int r3) {
-  int r[4] = { r0, r1, r2, r3 };
+PT_HD void node_step_nearfar(const PathState& ps, Trav& tv, Stack& st, Counters& ct, const float nx[4], const float fx[4], const float ny[4],
+                             const float fy[4], const float nz[4], const float fz[4], int r0, int r1, int r2, int r3) {
+  const int r[4] = { r0, r1, r2, r3 };
   cnt<CNT>(ct.nodeFetches);
   const float kFar = 3.0e38f;
-  float t[4];
+  ChildKey k[4];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-  for (int k = 0; k < 4; k++) {
-    const float tn = fmaxf_(fmaxf_(fminf_(ax[k], bx[k]), fminf_(ay[k], by[k])), fmaxf_(fminf_(az[k], bz[k]), ps.tmin));
-    const float tf = fminf_(fminf_(fmaxf_(ax[k], bx[k]), fmaxf_(ay[k], by[k])), fminf_(fmaxf_(az[k], bz[k]), tv.tbest));
-    t[k] = (tn <= tf * 1.0000005f && r[k] != kEmptyRef) ? tn : kFar;
+  for (int c = 0; c < 4; c++) {
+    const float tn = fmaxf_(fmaxf_(nx[c], ny[c]), fmaxf_(nz[c], ps.tmin));
+    const float tf = fminf_(fminf_(fx[c], fy[c]), fminf_(fz[c], tv.tbest));
+    const bool in = (c < 2) ? (tn <= tf * 1.0000005f) : (tn <= tf * 1.0000005f && r[c] != kEmptyRef);
+    k[c] = ChildKey::make(in ? tn : kFar, r[c]);
   }
-  sort2(t[0], r[0], t[1], r[1]); sort2(t[2], r[2], t[3], r[3]); sort2(t[0], r[0], t[2], r[2]);
-  sort2(t[1], r[1], t[3], r[3]); sort2(t[1], r[1], t[2], r[2]);
-  if (t[0] < kFar) {
+  ChildKey::order(k[0], k[1]); ChildKey::order(k[2], k[3]); ChildKey::order(k[0], k[2]);
+  ChildKey::order(k[1], k[3]); ChildKey::order(k[1], k[2]);
+  if (k[0].t() < kFar) {
     // one test for the step instead of one per push: do three more entries fit the stack's fast part?
     if (PT_STACK_ROOMY && st.roomy(tv.sp)) {
-      if (t[3] < kFar) { st.store_fast(tv.sp, r[3]); tv.sp++; }
-      if (t[2] < kFar) { st.store_fast(tv.sp, r[2]); tv.sp++; }
-      if (t[1] < kFar) { st.store_fast(tv.sp, r[1]); tv.sp++; }
+      if (k[3].t() < kFar) { st.store_fast(tv.sp, k[3].ref()); tv.sp++; }
+      if (k[2].t() < kFar) { st.store_fast(tv.sp, k[2].ref()); tv.sp++; }
+      if (k[1].t() < kFar) { st.store_fast(tv.sp, k[1].ref()); tv.sp++; }
     } else {
-      if (t[3] < kFar) { st.store(tv.sp, r[3]); tv.sp++; }
-      if (t[2] < kFar) { st.store(tv.sp, r[2]); tv.sp++; }
-      if (t[1] < kFar) { st.store(tv.sp, r[1]); tv.sp++; }
+      if (k[3].t() < kFar) { st.store(tv.sp, k[3].ref()); tv.sp++; }
+      if (k[2].t() < kFar) { st.store(tv.sp, k[2].ref()); tv.sp++; }
+      if (k[1].t() < kFar) { st.store(tv.sp, k[1].ref()); tv.sp++; }
     }
-    tv.node = r[0];
+    tv.node = k[0].ref();
   } else {
     trav_pop(tv, st);
   }
 }
-// The slab tests, the sort and the pushes of one four-child node whose 128-byte record is already in registers.
-template <bool CNT, class Stack>
-PT_HD void node_step_with(const PathState& ps, Trav& tv, Stack& st, Counters& ct, const v4& lox, const v4& loy, const v4& loz,
-                          const v4& hix, const v4& hiy, const v4& hiz, int r0, int r1, int r2, int r3) {
-  float ax[4], bx[4], ay[4], by[4], az[4], bz[4];
-  planes4(lox, tv.inv.x, tv.noi.x, ax); planes4(hix, tv.inv.x, tv.noi.x, bx);
-  planes4(loy, tv.inv.y, tv.noi.y, ay); planes4(hiy, tv.inv.y, tv.noi.y, by);
-  planes4(loz, tv.inv.z, tv.noi.z, az); planes4(hiz, tv.inv.z, tv.noi.z, bz);
-  node_step_planes<CNT>(ps, tv, st, ct, ax, bx, ay, by, az, bz, r0, r1, r2, r3);
+PT_HD void planes4(const v4& p, float inv, float noi, float out[4]) {
+  out[0] = fma_(p.x, inv, noi); out[1] = fma_(p.y, inv, noi); out[2] = fma_(p.z, inv, noi); out[3] = fma_(p.w, inv, noi);
 }
 // N64: the node loop fetches the 64-byte form of the nodes (pt_types.h Node64): four look-ups per lane instead of seven.
 // The decode is folded into the slab test: plane = corner + q * step, so
 //   t = (plane - o) / d = q * (step / d) + (corner - o) / d = fma(q, step * (1/d), fma(corner, 1/d, -o/d))
 // -- per node three multiplications and three fma, per plane one v_cvt_f32_ubyteN and the fma the uncompressed form needs as
-// well.  A template parameter, not a flag of the scene: with both decodes in one kernel the packet kernel ran 7-10 % slower
-// (113.4 / 119.9 ms against 105.5 / 108.4 ms on coffee at 64 spp), for either format.
+// well.  With d > 0 the lower plane of a box is the one the ray meets first, with d < 0 the upper one: fma is monotone in q,
+// so picking the word by the sign gives exactly min / max of the two distances.  A template parameter, not a flag of the
+// scene: with both decodes in one kernel the packet kernel ran 7-10 % slower, for either format.
 PT_HD void planes4q(uint32_t w, float step, float base, float out[4]) {
   out[0] = fma_((float)(w & 0xffu), step, base); out[1] = fma_((float)((w >> 8) & 0xffu), step, base);
   out[2] = fma_((float)((w >> 16) & 0xffu), step, base); out[3] = fma_((float)(w >> 24), step, base);
 }
 template <bool CNT, bool N64 = false, class Stack>
 PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
+  float nx[4], fx[4], ny[4], fy[4], nz[4], fz[4];
   if constexpr (N64) {
     const Node64 n = load_const(sc.nodes64 + tv.node);
     const float sx = n.sx * tv.inv.x, sy = n.sy * tv.inv.y, sz = n.sz * tv.inv.z;
     const float cx = fma_(n.ox, tv.inv.x, tv.noi.x), cy = fma_(n.oy, tv.inv.y, tv.noi.y), cz = fma_(n.oz, tv.inv.z, tv.noi.z);
-    float ax[4], bx[4], ay[4], by[4], az[4], bz[4];
-    planes4q(n.q[0], sx, cx, ax); planes4q(n.q[3], sx, cx, bx);
-    planes4q(n.q[1], sy, cy, ay); planes4q(n.q[4], sy, cy, by);
-    planes4q(n.q[2], sz, cz, az); planes4q(n.q[5], sz, cz, bz);
-    node_step_planes<CNT>(ps, tv, st, ct, ax, bx, ay, by, az, bz, n.ref[0], n.ref[1], n.ref[2], n.ref[3]);
+    const bool bx = tv.inv.x < 0.f, by = tv.inv.y < 0.f, bz = tv.inv.z < 0.f;      // the same for every node of a ray
+    planes4q(bx ? n.q[3] : n.q[0], sx, cx, nx); planes4q(bx ? n.q[0] : n.q[3], sx, cx, fx);
+    planes4q(by ? n.q[4] : n.q[1], sy, cy, ny); planes4q(by ? n.q[1] : n.q[4], sy, cy, fy);
+    planes4q(bz ? n.q[5] : n.q[2], sz, cz, nz); planes4q(bz ? n.q[2] : n.q[5], sz, cz, fz);
+    node_step_nearfar<CNT>(ps, tv, st, ct, nx, fx, ny, fy, nz, fz, n.ref[0], n.ref[1], n.ref[2], n.ref[3]);
   } else {
-    const Node128 npv = load_const(sc.nodes + tv.node);
-    node_step_with<CNT>(ps, tv, st, ct, npv.lox, npv.loy, npv.loz, npv.hix, npv.hiy, npv.hiz, npv.ref[0], npv.ref[1], npv.ref[2], npv.ref[3]);
+    const Node128 n = load_const(sc.nodes + tv.node);
+    float a[4], b[4];
+    planes4(n.lox, tv.inv.x, tv.noi.x, a); planes4(n.hix, tv.inv.x, tv.noi.x, b);
+    for (int c = 0; c < 4; c++) { nx[c] = fminf_(a[c], b[c]); fx[c] = fmaxf_(a[c], b[c]); }
+    planes4(n.loy, tv.inv.y, tv.noi.y, a); planes4(n.hiy, tv.inv.y, tv.noi.y, b);
+    for (int c = 0; c < 4; c++) { ny[c] = fminf_(a[c], b[c]); fy[c] = fmaxf_(a[c], b[c]); }
+    planes4(n.loz, tv.inv.z, tv.noi.z, a); planes4(n.hiz, tv.inv.z, tv.noi.z, b);
+    for (int c = 0; c < 4; c++) { nz[c] = fminf_(a[c], b[c]); fz[c] = fmaxf_(a[c], b[c]); }
+    node_step_nearfar<CNT>(ps, tv, st, ct, nx, fx, ny, fy, nz, fz, n.ref[0], n.ref[1], n.ref[2], n.ref[3]);
   }
 }
-
-#if defined(__HIPCC__)
-// Quad-cooperative node fetch (kernels whose node loop runs with the whole wave converged).  The L1 of a CU takes ONE per-lane
-// address per clock: a lane fetching its own 128-byte node with 7 x dwordx4 costs 7 look-ups, and with 64 lanes on 64
-// different nodes the address path, not the bytes, is what the node loop waits for (tools/micro/gather_coop.hip,
-// profiles/r03_gather_ceiling.txt).  Four adjacent lanes reading 64 contiguous bytes are one look-up, so the four lanes of a
-// quad fetch the nodes of the quad together: in round r all four read the node of the quad's lane r (lane p the quarters p
-// and p + 4 of its 8 x 16 bytes), and a 4 x 4 transpose inside the quad (two DPP butterfly stages, no LDS) hands every lane
-// the 7 quarters of its own node.  8 loads of 2 look-ups per (quad, round) with an active owner instead of 7 per active
-// lane; the values that reach node_step_with are the same bits.
-template <int BIT> __device__ __forceinline__ float quad_xchg(float send) {       // the value `send` of lane ^ (1 << BIT)
-  constexpr int ctrl = BIT == 0 ? 0xB1 : 0x4E;                                     // quad_perm [1,0,3,2] / [2,3,0,1]
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), ctrl, 0xf, 0xf, true));
-}
-// m[q] := what lane q of the quad held in m[own lane index]; every lane of the wave must be active here (DPP reads lanes)
-__device__ __forceinline__ void quad_transpose(float m[4], bool b0, bool b1) {
-  {
-    const float s01 = b0 ? m[0] : m[1], s23 = b0 ? m[2] : m[3];
-    const float r01 = quad_xchg<0>(s01), r23 = quad_xchg<0>(s23);
-    m[0] = b0 ? r01 : m[0]; m[1] = b0 ? m[1] : r01; m[2] = b0 ? r23 : m[2]; m[3] = b0 ? m[3] : r23;
-  }
-  {
-    const float s02 = b1 ? m[0] : m[2], s13 = b1 ? m[1] : m[3];
-    const float r02 = quad_xchg<1>(s02), r13 = quad_xchg<1>(s13);
-    m[0] = b1 ? r02 : m[0]; m[2] = b1 ? m[2] : r02; m[1] = b1 ? r13 : m[1]; m[3] = b1 ? m[3] : r13;
-  }
-}
-// Wave-collective: `active` lanes stand at the node tv.node; the others only help with the fetch.
-template <bool CNT, class Stack>
-__device__ __forceinline__ void trav_node_step_quad(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct, bool active) {
-  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const int p = lane & 3;
-  const int mine = active ? tv.node : -1;
-  const int o4[4] = { __builtin_amdgcn_mov_dpp(mine, 0x00, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(mine, 0x55, 0xf, 0xf, true),
-                      __builtin_amdgcn_mov_dpp(mine, 0xAA, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(mine, 0xFF, 0xf, 0xf, true) };   // quad_perm [r,r,r,r]
-  v4 a[2][4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    a[0][r] = mk4(0.f, 0.f, 0.f, 0.f); a[1][r] = mk4(0.f, 0.f, 0.f, 0.f);
-    if (o4[r] >= 0) {
-      const v4* src = reinterpret_cast<const v4*>(sc.nodes + o4[r]) + p;
-      a[0][r] = load_const(src); a[1][r] = load_const(src + 4);
-    }
-  }
-  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
-  v4 q[8];
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    float mx[4] = { a[h][0].x, a[h][1].x, a[h][2].x, a[h][3].x }, my[4] = { a[h][0].y, a[h][1].y, a[h][2].y, a[h][3].y };
-    float mz[4] = { a[h][0].z, a[h][1].z, a[h][2].z, a[h][3].z }, mw[4] = { a[h][0].w, a[h][1].w, a[h][2].w, a[h][3].w };
-    quad_transpose(mx, b0, b1); quad_transpose(my, b0, b1); quad_transpose(mz, b0, b1); quad_transpose(mw, b0, b1);
-#pragma unroll
-    for (int k = 0; k < 4; k++) q[4 * h + k] = mk4(mx[k], my[k], mz[k], mw[k]);
-  }
-  // Node128: lox loy loz hix | hiy hiz ref[4] (count, pad)
-  if (active) node_step_with<CNT>(ps, tv, st, ct, q[0], q[1], q[2], q[3], q[4], q[5], f2i(q[6].x), f2i(q[6].y), f2i(q[6].z), f2i(q[6].w));
-}
-#endif
 
 // One leaf (count x 48-byte triangle records) for a lane with tv.node < 0.  The records of up to four
 // triangles are fetched together (one memory round trip per chunk instead of one per triangle; slots past the
 // end of the leaf re-read its last record, which costs no extra line) and then tested in order.  A caller that
 // knows the leaf early (queuekernel.hip: from LDS) issues leaf_fetch4 for the first chunk itself, together with
 // its other loads.
-#ifndef PT_LEAF_PRED
-#define PT_LEAF_PRED 0      // measured: 233 ms against 218 ms at 128 spp -- the four exec-masked regions cost more than the look-ups they save
-#endif
 struct LeafChunk { v3 p0[4], e0[4], e1[4]; int mat[4], prim[4]; };
 PT_HD void leaf_fetch4(const SceneView& sc, int leafRef, int base, LeafChunk& ch) {
   const int first = leaf_first(leafRef), count = leaf_count(leafRef);
@@ -369,20 +320,10 @@ PT_HD void leaf_fetch4(const SceneView& sc, int leafRef, int base, LeafChunk& ch
 #pragma unroll
 #endif
   for (int j = 0; j < 4; j++) {
-#if PT_LEAF_PRED
-    // records past the end of the leaf are not requested at all: every per-lane request is a look-up in the CU's L1,
-    // whose rate (one per clock), not the bytes, is what per-lane gathers are bounded by
-    ch.p0[j] = mk3(0.f, 0.f, 0.f); ch.e0[j] = mk3(0.f, 0.f, 0.f); ch.e1[j] = mk3(0.f, 0.f, 0.f); ch.mat[j] = 0; ch.prim[j] = 0;
-    if (base + j < count) {
-      const Tri48 tpv = load_const(sc.tris + (first + base + j));
-      ch.p0[j] = tpv.p0; ch.e0[j] = tpv.e0; ch.e1[j] = tpv.e1; ch.mat[j] = tpv.mat; ch.prim[j] = tpv.prim;
-    }
-#else
     const int k = base + j < count ? base + j : count - 1;
     const Tri48 tpv = load_const(sc.tris + (first + k));
     const Tri48* tp = &tpv;
     ch.p0[j] = tp->p0; ch.e0[j] = tp->e0; ch.e1[j] = tp->e1; ch.mat[j] = tp->mat; ch.prim[j] = tp->prim;
-#endif
   }
 }
 template <bool CNT, class Stack>
