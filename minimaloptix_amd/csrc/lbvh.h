@@ -15,7 +15,8 @@ struct LbvhResult {
   float buildMs = 0.f;
 };
 
-// facePos: 9 floats per face (p0 p1 p2) in upload order; faceNrm: 9 per face; device pointers.
+// facePos: 9 floats per face (p0 p1 p2) in upload order; faceNrm: 9 per face; dFaceMat: face_mat_word(material id, SHADOW_*)
+// per face (pt_types.h); device pointers.
 // Allocates the result arrays with hipMalloc (caller frees with lbvh_free).
 // builder: 0 = Morton radix tree (Karras 2012), 1 = binned-SAH topology over the Morton order (pt_lbvh.h)
 hipError_t lbvh_build(hipStream_t stream, const float* dFacePos, const float* dFaceNrm, const int* dFaceHasNrm,

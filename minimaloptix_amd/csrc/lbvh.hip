@@ -95,7 +95,7 @@ __global__ void k_leaves(int n, const uint64_t* __restrict__ keys, const float* 
   const float* p = facePos + 9 * (size_t)f;
   const v3 p0 = mk3(p[0], p[1], p[2]), p1 = mk3(p[3], p[4], p[5]), p2 = mk3(p[6], p[7], p[8]);
   Tri48 t;
-  t.p0 = p0; t.e0 = p1 - p0; t.e1 = p0 - p2; t.mat = faceMat[f]; t.prim = f; t.pad = 0;
+  t.p0 = p0; t.e0 = p1 - p0; t.e1 = p0 - p2; t.mat = faceMat[f] & ((1 << kFaceMatBits) - 1); t.prim = f; t.shadow = faceMat[f] >> kFaceMatBits;
   tris[k] = t;
   TriShade sh;
   sh.n0 = mk3(0, 0, 0); sh.n1 = sh.n0; sh.n2 = sh.n0; sh.hasNormals = 0; sh.pad1 = 0; sh.pad2 = 0;

@@ -85,6 +85,7 @@ size_t queuekernel_cold_bytes(int nBlocks);
 size_t queuekernel_overflow_ints(int nBlocks, int ovfDepth);
 hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading);
 int packetkernel_lds_stack_entries();
+int packetkernel_slots();             // path slots per workgroup (variant 4)
 size_t packetkernel_cold_bytes(int nBlocks);
 size_t packetkernel_overflow_ints(int nBlocks, int ovfDepth);
 hipError_t launch_packetkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading);

@@ -296,7 +296,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   // items run out there are plenty, before that only the ones kept free here.  A launch under 1e8 samples (an 8-way share
   // of the benchmark frame) is short enough for its tail to matter more than the throughput of 64 more paths per pool:
   // 66.7 ms with 448 of 512 slots in use against 70.1 ms with all of them; a 4-way share: 130.3 against 125.0 ms.
-  a.slotsInUse = c->optSlotsInUse >= 0 ? c->optSlotsInUse : (usePacket && c->optAuxDepth > 0 && nSamples < 1.0e8 ? 448 : 0);
+  a.slotsInUse = c->optSlotsInUse >= 0 ? c->optSlotsInUse : (usePacket && c->optAuxDepth > 0 && nSamples < 1.0e8 ? packetkernel_slots() * 7 / 8 : 0);
   a.auxDepth = usePacket ? c->optAuxDepth : 0;
   a.watchdogTicks = (unsigned long long)c->optWatchdogMs * 100000ull;      // s_memrealtime counts at 100 MHz
   if (usePacket) {
@@ -698,7 +698,12 @@ int moptix_build_accel(moptix_context c, const char* kind) {
     HIPCHK(c, c->dFacePos.upload(c->facePos, c->stream), "upload face positions");
     HIPCHK(c, c->dFaceNrm.upload(c->faceNrm, c->stream), "upload face normals");
     HIPCHK(c, c->dFaceHasNrm.upload(c->faceHasNrm, c->stream), "upload face flags");
-    HIPCHK(c, c->dFaceMat.upload(c->faceMat, c->stream), "upload face materials");
+    {
+      std::vector<int> words(c->faceMat.size());      // material id + what the face is to a shadow ray (pt_types.h SHADOW_*)
+      for (size_t f = 0; f < words.size(); f++) { const DevMaterial& m = c->mats[c->faceMat[f]]; words[f] = face_mat_word(c->faceMat[f], shadow_class(m.kind, m.brdfType)); }
+      HIPCHK(c, c->dFaceMat.upload(words, c->stream), "upload face materials");
+      HIPCHK(c, hipStreamSynchronize(c->stream), "sync face material upload");      // the staging vector dies here
+    }
     size_t glassFaces = 0;
     for (int m : c->faceMat) glassFaces += (c->mats[m].kind == MAT_GLASS || (c->mats[m].kind == MAT_DISNEY && c->mats[m].brdfType == BRDF_GLASS)) ? 1 : 0;
     c->glassFaceShare = (double)glassFaces / (double)nFaces;
@@ -774,7 +779,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "auto_packet")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "auto_packet in {0,1}"); c->optAutoPacket = value; }
   else if (!strcmp(name, "analytic_queue")) { if (value < -1 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "analytic_queue in {-1,0,1}"); c->optAnalyticQueue = value; }
   else if (!strcmp(name, "aux_depth")) { if (value < 0 || value > 100000) return fail(c, MOPTIX_ERR_INVALID, "aux_depth in [0,100000]"); c->optAuxDepth = value; }
-  else if (!strcmp(name, "slots_in_use")) { if (value < -1 || value > 512) return fail(c, MOPTIX_ERR_INVALID, "slots_in_use in [-1,512]"); c->optSlotsInUse = value; }
+  else if (!strcmp(name, "slots_in_use")) { if (value < -1 || value > 1024) return fail(c, MOPTIX_ERR_INVALID, "slots_in_use in [-1,1024]"); c->optSlotsInUse = value; }
   else if (!strcmp(name, "builder")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "builder in {0,1}"); if (value != c->optBuilder) c->accelBuilt = false; c->optBuilder = value; }
   else if (!strcmp(name, "fast_shading")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "fast_shading in {0,1}"); c->optFastShading = value; }
   else if (!strcmp(name, "node_format")) { if (value != 0 && value != 64 && value != 128) return fail(c, MOPTIX_ERR_INVALID, "node_format in {0,64,128}"); if (value != c->optNodeFormat) c->formatDecided = false; c->optNodeFormat = value; }

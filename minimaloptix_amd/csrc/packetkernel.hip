@@ -31,19 +31,34 @@ namespace {
 
 constexpr int kBlockThreads = 256;
 constexpr int kWaves = kBlockThreads / 64;
-#ifndef PT_KP
-#define PT_KP 128
+// Path slots per wave and LDS stack entries per slot: what a workgroup's third of the CU's LDS (54,592 bytes for three workgroups,
+// tools/micro/lds_limit.hip) is spent on.  A slot costs 32 B of ray + 4 (entries + 1) B of stack + 12 B of ring space.  Measured on
+// coffee at 64 spp, same bits (profiles/r04_slots.txt): 512 slots x 11 entries 95.3 ms, 544 x 10 93.8, 576 x 9 93.3, 608 x 8 93.9,
+// 640 x 7 94.5 -- more paths in flight against more stack entries spilled to HBM.  (queuekernel.hip keeps its own 512 x 11.)
+#ifndef PT_PK_KP
+#define PT_PK_KP 144
 #endif
-#ifndef PT_STACKN
-#define PT_STACKN 11
+#ifndef PT_PK_STACKN
+#define PT_PK_STACKN 9
 #endif
+#define PT_KP PT_PK_KP
+#define PT_STACKN PT_PK_STACKN
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 3
 #endif
 constexpr int kP = PT_KP;               // slots per wave
 constexpr int kStackN = PT_STACKN;      // LDS stack entries per slot; deeper levels spill to HBM
 constexpr int kWavesPerSimd = PT_WAVES_PER_SIMD;   // occupancy target: 3 workgroups per CU (VGPR <= 168, LDS <= 53 KB)
-constexpr int ring_capacity(int n) { int c = 1; while (c < n) c <<= 1; return c; }
+// Rings hold exactly NS entries (a slot sits in at most one ring): sized to the next power of two they would cost 640 -> 1024
+// entries each and the workgroup its third of the CU's LDS.  An index is head + count + rank < 2 NS: one conditional subtract.
+constexpr int ring_capacity(int n) { return n; }
+template <int NS> __device__ __forceinline__ int ring_wrap(int i) {
+  if constexpr ((NS & (NS - 1)) == 0) return i & (NS - 1); else return i >= NS ? i - NS : i;
+}
+constexpr int kSlotBits = 10;           // slot ids in packed words (borrowed slots, parent of a borrowed slot)
+constexpr int kSlotMask = (1 << kSlotBits) - 1;
+static_assert(PT_KP * kWaves <= (1 << kSlotBits), "slot ids are 10 bits");
+
 
 // pool-wide queues first (they index PoolLds::queue); Q_NODE / Q_LEAF are per-wave rings (WavePriv)
 enum { Q_SHADE = 0, Q_GEN = 1, kNumQ = 2, Q_NODE = 2, Q_LEAF = 3, DEST_DONE = 4, DEST_NONE = -1 };
@@ -138,18 +153,19 @@ constexpr int kNShShift = 10;         // bits 10-11: shadow rays in the packet
 constexpr int kNRayShift = 12;        // bits 12-13: rays in the packet - 1
 constexpr int kStatShift = 14;        // bits 14-19: per shadow ray 0 = attenuation (1,1,1), 1 = (0,0,0), 2 = tinted (att row)
 constexpr int kHasAux = 1 << 21;      // path slot: the packet's shadow rays are being traced by borrowed slots (join before shading)
-constexpr int kAuxSlot = 1 << 22;     // borrowed slot: one shadow ray of the path slot named in bits 16-20 and 23-26 (aux_parent)
+constexpr int kAuxSlot = 1 << 22;     // borrowed slot: one shadow ray of the path slot named in bits 16-20 and 23-27 (aux_parent)
 constexpr int kPendShift = 23;        // bits 23-24: pend rows the next visit has to read (= the packet's shadow rays, wherever they are traced)
 // Join of a path slot with its borrowed slots, in the path slot's flag word: only these bits are touched by other
 // waves (LDS atomics), so the owner updates the rest of the word with atomics too while kHasAux is set (store_flags).
 constexpr int kJoinShift = 25;        // bits 25-26: borrowed slots whose shadow ray is still out
 constexpr int kArrived = 1 << 27;     // the path slot's own ray is done (or it had none)
 constexpr int kJoinMask = (3 << kJoinShift) | kArrived;
-__device__ __forceinline__ int aux_parent_bits(int parent) { return ((parent & 31) << 16) | ((parent >> 5) << 23); }
-__device__ __forceinline__ int aux_parent(int fl) { return ((fl >> 16) & 31) | (((fl >> 23) & 15) << 5); }
-// SlotCold::ctl.w bit 7: the path holds three borrowed slots (9 bits each in thr.w), kept until the path ends
+__device__ __forceinline__ int aux_parent_bits(int parent) { return ((parent & 31) << 16) | ((parent >> 5) << 23); }      // a borrowed slot uses neither its pend / join bits nor kArrived
+__device__ __forceinline__ int aux_parent(int fl) { return ((fl >> 16) & 31) | (((fl >> 23) & 31) << 5); }
+// SlotCold::ctl.w bit 7: the path holds three borrowed slots (10 bits each in thr.w), kept until the path ends
 constexpr int kCtlHoldsAux = 1 << 7;
 constexpr int kHasScale = 1 << 20;    // SlotCold::bsc holds the continuation's weight (a Disney bounce)
+constexpr int kPrimUnknown = 0x7fffffff;      // leaf pass: the slot holds a hit whose primitive id has not been read (above every real id)
 constexpr int kSwitchRef = (int)0x80000000;   // "node" of a slot whose ray ended while another ray of the packet is pending
 __device__ __forceinline__ int fl_cur(int fl) { return (fl >> kCurShift) & 3; }
 __device__ __forceinline__ int fl_nsh(int fl) { return (fl >> kNShShift) & 3; }
@@ -210,12 +226,12 @@ __device__ __forceinline__ int route(int node, int kind, int bestPrim) {
 // shadow ray goes to its own borrowed slot, to be traced at the same time as the continuation.
 struct SlotSink {
   SlotCold* cold; int slot; v4* nodeA; v4* nodeB; int (*stack)[kStackN + 1]; const PathState* ps; int root;
-  int axp;                              // this path's three borrowed slots (9 bits each) or -1
+  int axp;                              // this path's three borrowed slots (10 bits each) or -1
   __device__ __forceinline__ void shadow(int j, v3 d, float tmax, v3 w, float inv) const {
     SlotCold* cw = cold + slot;
     slot_store(&cw->pend[j], mk4(w.x, w.y, w.z, inv));
     if (axp >= 0) {
-      const int ax = (axp >> (9 * j)) & 511;
+      const int ax = (axp >> (kSlotBits * j)) & kSlotMask;
       nodeA[ax] = mk4(ps->o.x, ps->o.y, ps->o.z, tmax); nodeB[ax] = mk4(d.x, d.y, d.z, i2f(root));
       stack[ax][0] = kAuxSlot | kShadowRay | kShadeFlag | (1 << kNShShift) | aux_parent_bits(slot);      // a packet of one shadow ray
     } else if (j == 0) { nodeA[slot] = mk4(ps->o.x, ps->o.y, ps->o.z, tmax); nodeB[slot] = mk4(d.x, d.y, d.z, i2f(root)); }   // ps->o: the hit point
@@ -228,7 +244,6 @@ struct SlotSink {
 template <bool CNT, bool SHARED, bool FAST = false, bool NEAR = false, bool N64 = false>
 __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(const LaunchArgs a) {
   constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
-  constexpr int RC = ring_capacity(NS);                  // ring capacity (power of two >= NS)
   __shared__ PoolLds<NS> sPool[SHARED ? 1 : kWaves];
   __shared__ WavePriv<NS> sPriv[kWaves];
 
@@ -253,15 +268,15 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
   [[maybe_unused]] auto q_push = [&](int q, bool pred, int slot) {
     const unsigned long long m = __ballot(pred);
     if (m == 0ull) return;
-    if (pred) W.queue[q][(qHead[q] + qCount[q] + lane_rank(m)) & (RC - 1)] = (unsigned short)slot;
+    if (pred) W.queue[q][ring_wrap<NS>(qHead[q] + qCount[q] + lane_rank(m))] = (unsigned short)slot;
     qCount[q] += __popcll(m);
   };
   auto q_pop = [&](int q, bool want) -> int {
     const unsigned long long m = __ballot(want);
     const int n = min(__popcll(m), qCount[q]);
     int slot = -1;
-    if (want) { const int r = lane_rank(m); if (r < n) slot = W.queue[q][(qHead[q] + r) & (RC - 1)]; }
-    qHead[q] = (qHead[q] + n) & (RC - 1);
+    if (want) { const int r = lane_rank(m); if (r < n) slot = W.queue[q][ring_wrap<NS>(qHead[q] + r)]; }
+    qHead[q] = ring_wrap<NS>(qHead[q] + n);
     qCount[q] -= n;
     return slot;
   };
@@ -385,7 +400,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     {
       const unsigned long long m = __ballot(dest == Q_NODE);
       if (m != 0ull) {
-        if (dest == Q_NODE) myNodeQ[(nqHead + nqCount + lane_rank(m)) & (RC - 1)] = (unsigned short)slot;
+        if (dest == Q_NODE) myNodeQ[ring_wrap<NS>(nqHead + nqCount + lane_rank(m))] = (unsigned short)slot;
         nqCount += __popcll(m);
       }
     }
@@ -431,10 +446,14 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       leaf_fetch4(sc, isSwitch ? make_leaf_ref(0, 1) : node0, 0, ch);
       v4 wr = mk4(0.f, 0.f, 1.f, 0.f), wn = mk4(0.f, 0.f, 1.f, 0.f);
       const bool more = fl_more(fl);
-      if (more) { wn = slot_load(&cs->ray[cur]); PT_ROWS(2, 1); }       // ray cur+1 of the packet sits in ray[cur]: needed if this ray ends here
+      // ray cur+1 of the packet sits in ray[cur]: needed if this ray ends here -- a ray switch, a shadow ray (its any-hit program may
+      // end it at any leaf) or a leaf reached with an empty stack; a radiance ray with entries on its stack goes on after this leaf
+      if (more && (isSwitch || shadow || (fl & kSpMask) == 0)) { wn = slot_load(&cs->ray[cur]); PT_ROWS(2, 1); }
       if (!isSwitch) {
         if (shadow) { if (fl_stat(fl, cur) == 2) { wr = slot_load(&cs->att[cur]); PT_ROWS(2, 1); } }
-        else if (hitValid) { wr = slot_load(&cs->hit); PT_ROWS(2, 1); }
+        // the continuation's hit row stays where it is: tbest (LDS) decides every candidate except one at EXACTLY tbest, and
+        // only then the primitive id of the hit the slot holds is needed (below).  The row is in a 100 MB pool, the slowest
+        // fetch of this pass by far.
       }
       // the packet's next ray: same origin, restart at the root
       auto next_ray = [&](int flags) {
@@ -457,8 +476,8 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         tv.node = node0; tv.sp = fl & kSpMask;
         tv.bestTri = -1; tv.bestPrim = -1; tv.beta = 0.f; tv.gamma = 0.f; tv.att = mk3(1.f, 1.f, 1.f);
         if (shadow) { if (fl_stat(fl, cur) == 2) { tv.att = mk3(wr.x, wr.y, wr.z); if (sc.shadowNearest) tv.bestPrim = f2i(wr.w); } }
-        else if (hitValid) { tv.bestTri = f2i(wr.x); tv.bestPrim = f2i(wr.y); tv.beta = wr.z; tv.gamma = wr.w; }
-        const int oldTri = tv.bestTri, oldPrim = tv.bestPrim;
+        else if (hitValid) tv.bestPrim = kPrimUnknown;       // "some primitive at tbest": any candidate at exactly tbest passes potential() for now
+        const int oldPrim = tv.bestPrim;
         const v3 oldAtt = tv.att;
         SlotStack st = make_stack(slot);
         trav_leaf_step_fetched<CNT>(sc, ps, tv, st, ct, ch);
@@ -475,10 +494,16 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
             nfl = (nfl & ~(3 << (kStatShift + 2 * cur))) | ((zero ? 1 : 2) << (kStatShift + 2 * cur));
             if (!zero) { slot_store(&cold[slot].att[cur], mk4(tv.att.x, tv.att.y, tv.att.z, 0.f)); PT_ROWS(3, 1); }
           }
-        } else if (tv.bestTri != oldTri || tv.bestPrim != oldPrim) {
-          // most leaf visits find nothing nearer: the hit row is only written when it changed (beta / gamma change with bestTri)
-          slot_store(&cold[slot].hit, mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma)); PT_ROWS(3, 1);
-          nfl |= kHitValid | kShadeFlag;
+        } else if (tv.bestPrim != oldPrim) {
+          // most leaf visits find nothing nearer: the hit row is only written when it changed (primitive ids are unique, so a new
+          // hit is a new bestPrim).  A candidate at exactly the old tbest ties with the hit the row holds: the lower primitive id
+          // wins (rule D5), and this is the one case that reads the row.
+          bool keep = true;
+          if (hitValid && tv.tbest == na.w) { const v4 held = slot_load(&cs->hit); PT_ROWS(2, 1); keep = !(f2i(held.y) < tv.bestPrim); }
+          if (keep) {
+            slot_store(&cold[slot].hit, mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma)); PT_ROWS(3, 1);
+            nfl |= kHitValid | kShadeFlag;
+          }
         }
         if (tv.node == kTravDone && more) {
           next_ray(nfl);                                                    // this ray is done, the packet is not: on to its next ray
@@ -520,7 +545,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     Packet pk; packet_clear(pk);
     v3 att[kPacketShadows] = { mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f) };
-    int axp = -1;                                      // the three slots this path has borrowed for its shadow rays (9 bits each), -1 = none
+    int axp = -1;                                      // the three slots this path has borrowed for its shadow rays (10 bits each), -1 = none
     if (have) {
       const SlotCold* cs = cold + slot;
       const int fl = W.stack[slot][0];
@@ -540,7 +565,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         wp[i] = mk4(0.f, 0.f, 0.f, 0.f); wa[i] = mk4(1.f, 1.f, 1.f, 0.f);
         if (i < nSh) {
           wp[i] = slot_load(&cs->pend[i]); PT_ROWS(0, 1);
-          const int ax = (axp >> (9 * i)) & 511;                 // only used with hadAux
+          const int ax = (axp >> (kSlotBits * i)) & kSlotMask;                 // only used with hadAux
           const int stt = hadAux ? fl_stat(W.stack[ax][0], 0) : fl_stat(fl, i);
           if (stt == 2) { wa[i] = hadAux ? slot_load(&cold[ax].att[0]) : slot_load(&cs->att[i]); PT_ROWS(0, 1); }
           else if (stt == 1) wa[i] = mk4(0.f, 0.f, 0.f, 0.f);
@@ -603,7 +628,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       SlotCold* cw = cold + slot;
       // borrowed slots go back when the path has ended (the lane may hold a new path's camera ray by now)
       if (axp >= 0 && !(ps.mode == M_TRACE && ps.depth >= a.auxDepth)) {
-        for (int j = 0; j < kPacketShadows; j++) { const int ax = (axp >> (9 * j)) & 511; atomicOr(&W.freeMask[ax >> 5], 1u << (ax & 31)); }
+        for (int j = 0; j < kPacketShadows; j++) { const int ax = (axp >> (kSlotBits * j)) & kSlotMask; atomicOr(&W.freeMask[ax >> 5], 1u << (ax & 31)); }
         atomicAdd(&W.nFree, kPacketShadows);
         axp = -1;
       }
@@ -618,12 +643,12 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
             while (cur != 0u && got < kPacketShadows) {
               const int b = __builtin_ctz(cur);
               const unsigned int prev = atomicAnd(&W.freeMask[wi], ~(1u << b));       // claims the bit if it is still there
-              if (prev & (1u << b)) { pack |= (wi * 32 + b) << (9 * got); got++; }
+              if (prev & (1u << b)) { pack |= (wi * 32 + b) << (kSlotBits * got); got++; }
               cur = prev & ~(1u << b);
             }
           }
           if (got == kPacketShadows) { axpNext = pack; atomicSub(&W.nFree, kPacketShadows); }
-          else for (int j = 0; j < got; j++) { const int ax = (pack >> (9 * j)) & 511; atomicOr(&W.freeMask[ax >> 5], 1u << (ax & 31)); }
+          else for (int j = 0; j < got; j++) { const int ax = (pack >> (kSlotBits * j)) & kSlotMask; atomicOr(&W.freeMask[ax >> 5], 1u << (ax & 31)); }
         }
       }
       i4 ctl; ctl.x = ps.item; ctl.y = ps.depth; ctl.z = (int)ps.seed;
@@ -680,7 +705,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       }
     }
     if (auxOn && __ballot(useAux) != 0ull) {                // the borrowed slots start at the root, with this wave
-      for (int j = 0; j < kPacketShadows; j++) local_push((useAux && j < pk.nShadow) ? Q_NODE : DEST_NONE, (axp >> (9 * j)) & 511);
+      for (int j = 0; j < kPacketShadows; j++) local_push((useAux && j < pk.nShadow) ? Q_NODE : DEST_NONE, (axp >> (kSlotBits * j)) & kSlotMask);
     }
     if constexpr (!SHARED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     PT_SUB(tBStore);
@@ -718,7 +743,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         if (ns < 0) {
           const int r = lane_rank(m);
           if (r < n) {
-            ns = myNodeQ[(nqHead + r) & (RC - 1)];
+            ns = myNodeQ[ring_wrap<NS>(nqHead + r)];
             const v4 na = W.nodeA[ns], nb = W.nodeB[ns];
             const int spw = W.stack[ns][0];
             nray.o = mk3(na.x, na.y, na.z); ntv.tbest = na.w;
@@ -729,7 +754,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
             ntv.sp = spw & kSpMask; nsFlag = spw & ~kSpMask;
           }
         }
-        nqHead = (nqHead + n) & (RC - 1); nqCount -= n;
+        nqHead = ring_wrap<NS>(nqHead + n); nqCount -= n;
       }
     }
     const int nActive = __popcll(__ballot(ns >= 0));
@@ -754,7 +779,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         const int q = Q_SHADE + d;
         for (int base = 0; base < obCount[d]; base += 64) {
           const int i = base + lane;
-          if (i < obCount[d]) W.queue[q][(qHead[q] + qCount[q] + i) & (RC - 1)] = sPriv[wave].outbox[d][i];
+          if (i < obCount[d]) W.queue[q][ring_wrap<NS>(qHead[q] + qCount[q] + i)] = sPriv[wave].outbox[d][i];
         }
         qCount[q] += obCount[d]; obCount[d] = 0;
       }
@@ -826,6 +851,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
 }  // namespace
 
 int packetkernel_lds_stack_entries() { return kStackN; }
+int packetkernel_slots() { return kP * kWaves; }
 size_t packetkernel_cold_bytes(int nBlocks) { return (size_t)nBlocks * kWaves * kP * sizeof(SlotCold); }
 size_t packetkernel_overflow_ints(int nBlocks, int ovfDepth) { return (size_t)nBlocks * kWaves * kP * (size_t)ovfDepth; }
 

@@ -85,6 +85,20 @@ PT_HD void shadow_candidate(const SceneView& sc, int mat, float t, int prim, flo
   att = (m.brdfType == BRDF_GLASS) ? m.color : mk3(0.f, 0.f, 0.f);
 }
 
+// The same two for a triangle, whose record says what it is to a shadow ray (Tri48::shadow): only a glass surface's colour is
+// still read from the material table.
+PT_HD bool shadow_any_hit_tri(const SceneView& sc, int cls, int mat, v3& att) {
+  if (cls == SHADOW_NONE) return false;
+  if (cls == SHADOW_GLASS) { att = att * load_const(&sc.mats[mat].color); return false; }
+  att = mk3(0.f, 0.f, 0.f);
+  return true;
+}
+PT_HD void shadow_candidate_tri(const SceneView& sc, int cls, int mat, float t, int prim, float tmin, float& tbest, int& bestPrim, v3& att) {
+  if (cls == SHADOW_NONE || !potential(t, prim, tmin, tbest, bestPrim)) return;
+  tbest = t; bestPrim = prim;
+  att = (cls == SHADOW_GLASS) ? load_const(&sc.mats[mat].color) : mk3(0.f, 0.f, 0.f);
+}
+
 // 1/d for the slab planes.  A direction component below 1e-30 in magnitude is treated as +-1e-30 so that
 // plane*inv and o*inv stay finite (inf - inf would poison the planes); over any t the scene allows, that moves
 // the ray by less than 1e-29, far inside the padding of the boxes.
@@ -313,7 +327,7 @@ PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, St
 // end of the leaf re-read its last record, which costs no extra line) and then tested in order.  A caller that
 // knows the leaf early (queuekernel.hip: from LDS) issues leaf_fetch4 for the first chunk itself, together with
 // its other loads.
-struct LeafChunk { v3 p0[4], e0[4], e1[4]; int mat[4], prim[4]; };
+struct LeafChunk { v3 p0[4], e0[4], e1[4]; int mat[4], prim[4], shadow[4]; };
 PT_HD void leaf_fetch4(const SceneView& sc, int leafRef, int base, LeafChunk& ch) {
   const int first = leaf_first(leafRef), count = leaf_count(leafRef);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -323,7 +337,7 @@ PT_HD void leaf_fetch4(const SceneView& sc, int leafRef, int base, LeafChunk& ch
     const int k = base + j < count ? base + j : count - 1;
     const Tri48 tpv = load_const(sc.tris + (first + k));
     const Tri48* tp = &tpv;
-    ch.p0[j] = tp->p0; ch.e0[j] = tp->e0; ch.e1[j] = tp->e1; ch.mat[j] = tp->mat; ch.prim[j] = tp->prim;
+    ch.p0[j] = tp->p0; ch.e0[j] = tp->e0; ch.e1[j] = tp->e1; ch.mat[j] = tp->mat; ch.prim[j] = tp->prim; ch.shadow[j] = tp->shadow;
   }
 }
 template <bool CNT, class Stack>
@@ -348,8 +362,8 @@ PT_HD void trav_leaf_step_fetched(const SceneView& sc, const PathState& ps, Trav
                 tv.tbest = t; tv.bestPrim = triBase + ch.prim[j]; tv.bestTri = first + base + j; tv.beta = be; tv.gamma = ga;
               }
             } else if (sc.shadowNearest) {
-              shadow_candidate(sc, ch.mat[j], t, triBase + ch.prim[j], ps.tmin, tv.tbest, tv.bestPrim, tv.att);
-            } else if (shadow_any_hit(sc, ch.mat[j], tv.att)) terminated = true;
+              shadow_candidate_tri(sc, ch.shadow[j], ch.mat[j], t, triBase + ch.prim[j], ps.tmin, tv.tbest, tv.bestPrim, tv.att);
+            } else if (shadow_any_hit_tri(sc, ch.shadow[j], ch.mat[j], tv.att)) terminated = true;
           }
         }
       }

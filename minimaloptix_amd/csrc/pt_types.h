@@ -75,7 +75,7 @@ static_assert(sizeof(Node64) == 64, "Node64 must be 64 bytes");
 struct alignas(16) Tri48 {
   v3 p0; int mat;        // material id of the face
   v3 e0; int prim;       // e0 = p1-p0 ; prim = original face index (upload order)
-  v3 e1; int pad;        // e1 = p0-p2
+  v3 e1; int shadow;     // e1 = p0-p2 ; what the face is to a shadow ray (SHADOW_*, from its material at build time)
 };
 static_assert(sizeof(Tri48) == 48, "Tri48 must be 48 bytes");
 
@@ -116,6 +116,16 @@ static_assert(sizeof(DevLight) == 80, "DevLight must be 80 bytes");
 enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_GLASS = 2, MAT_DISNEY = 3, MAT_LIGHT = 4 };
 enum { BRDF_NORMAL = 0, BRDF_GLASS = 1 };
 enum { LIGHT_SPHERE = 0, LIGHT_QUAD = 1 };
+// What a primitive is to a shadow ray (disneyAnyHit, Material.cu:225-232): no any-hit program at all (lights, non-Disney
+// materials), an opaque Disney surface (attenuation 0, rtTerminateRay) or a Disney GLASS surface (attenuation *= colour).  The
+// builder writes it into every triangle record, so that a shadow ray's leaf visit needs the material table only for the
+// colour of a glass surface: the fetch of the material behind a hit triangle was a second dependent round trip inside the pass.
+// Materials are fixed once the acceleration structure is built (moptix_add_material invalidates it).
+enum { SHADOW_NONE = 0, SHADOW_OPAQUE = 1, SHADOW_GLASS = 2 };
+PT_HD int shadow_class(int kind, int brdfType) { return kind != MAT_DISNEY ? SHADOW_NONE : (brdfType == BRDF_GLASS ? SHADOW_GLASS : SHADOW_OPAQUE); }
+// the builder's per-face material input: material id in the low bits, SHADOW_* above them
+constexpr int kFaceMatBits = 28;
+PT_HD int face_mat_word(int mat, int shadow) { return mat | (shadow << kFaceMatBits); }
 
 // Material record: program parameters + the Disney constants that depend on the
 // material only (disney.h:49-77 evaluates them per call; they are pure functions of

@@ -171,6 +171,7 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
     const v3 p0 = mk3(p[0], p[1], p[2]), p1 = mk3(p[3], p[4], p[5]), p2 = mk3(p[6], p[7], p[8]);
     Tri48 t; memset(&t, 0, sizeof(t));
     t.p0 = p0; t.e0 = p1 - p0; t.e1 = p0 - p2; t.mat = s.faceMat[f]; t.prim = f;
+    { const DevMaterial dm = make_dev_material(s.materials[s.faceMat[f]]); t.shadow = shadow_class(dm.kind, dm.brdfType); }
     out.tris[k] = t;
     TriShade sh; memset(&sh, 0, sizeof(sh));
     if (s.faceNrm && s.faceHasNrm && s.faceHasNrm[f]) {
