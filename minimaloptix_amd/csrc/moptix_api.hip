@@ -199,8 +199,8 @@ int check_ready(moptix_context c) {
 }
 
 int read_stats(moptix_context c, moptix_stats* stats) {
-  unsigned long long h[40 + 768 + 8];
-  HIPCHK(c, hipMemcpy(h, c->dCounters.p, sizeof(unsigned long long) * (c->dCounters.n >= 816 ? 816 : 40), hipMemcpyDeviceToHost), "read counters");
+  unsigned long long h[40 + 768 + 8 + 2 * kCensusRegions] = {};
+  HIPCHK(c, hipMemcpy(h, c->dCounters.p, sizeof(unsigned long long) * (c->dCounters.n >= 816 + 2 * kCensusRegions ? 816 + 2 * kCensusRegions : (c->dCounters.n >= 816 ? 816 : 40)), hipMemcpyDeviceToHost), "read counters");
   stats->samples = h[0]; stats->primaryRays = h[1]; stats->bounceRays = h[2]; stats->shadowRays = h[3];
   stats->nodeFetches = h[4]; stats->triTests = h[5]; stats->closestHits = h[6]; stats->lightLoads = h[7];
   stats->analyticTests = h[8]; stats->traversalSteps = h[9]; stats->activeLaneSteps = h[10];
@@ -234,6 +234,15 @@ int read_stats(moptix_context c, moptix_stats* stats) {
     }
     if (h[22]) fprintf(stderr, "[moptix] node steps %llu (%.1f lanes avg), leaf passes %llu (%.1f lanes avg)\n", h[9] - h[22],
             (double)(h[10] - h[23]) / (double)(h[9] - h[22]), h[22], (double)h[23] / (double)h[22]);
+    if (c->dCounters.n >= 816 + 2 * kCensusRegions && h[816 + kCensusRegions]) {      // lane census of the divergent regions (pt_path.h census<>)
+      static const char* names[kCensusRegions] = { "result visit (on_result_packet)", "  miss", "  closest hit (hit_attributes + material)", "    light material",
+        "    depth cap", "    lambertian", "    metal", "    glass", "    disney GLASS", "    disney (on_lights_packet)", "      light 0 faces: pdf + eval", "      light 1 faces: pdf + eval",
+        "      light 2 faces: pdf + eval", "      bounce: pdf + eval", "new work item (begin_sample)", "leaf pass: triangle 0 tested", "leaf pass: triangle 1 tested",
+        "leaf pass: triangle 2 tested", "leaf pass: triangle 3 tested", "  triangle hit accepted by tri_test", "  shadow result folded", "      light draw (per light)", "      bounce: disney_sample", "" };
+      fprintf(stderr, "[moptix] lane census: region | waves that entered | lanes that entered | lanes per wave (of 64)\n");
+      for (int i = 0; i < kCensusRegions; i++)
+        if (h[816 + kCensusRegions + i]) fprintf(stderr, "[moptix]   %-46s %12llu %14llu %6.1f\n", names[i], h[816 + kCensusRegions + i], h[816 + i], (double)h[816 + i] / (double)h[816 + kCensusRegions + i]);
+    }
   }
   return MOPTIX_OK;
 }
@@ -358,8 +367,8 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   }
   a.workCounter = c->dWork.p;
   if (counted) {
-    HIPCHK(c, c->dCounters.ensure(40 + 768 + 8), "alloc counters");
-    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * (40 + 768 + 8), c->stream), "zero counters");
+    HIPCHK(c, c->dCounters.ensure(40 + 768 + 8 + 2 * kCensusRegions), "alloc counters");
+    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(unsigned long long) * (40 + 768 + 8 + 2 * kCensusRegions), c->stream), "zero counters");
     HIPCHK(c, hipMemsetAsync(c->dCounters.p + 36, 0xff, sizeof(unsigned long long) * 2, c->stream), "init min counters");
     a.counters = c->dCounters.p;
   }

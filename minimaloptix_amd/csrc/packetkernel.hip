@@ -145,7 +145,14 @@ typedef __attribute__((address_space(3))) int lds_int;
 // overflow path into one flat_load).
 // stack[slot][0]: bits 0-7 stack pointer, the rest describes the packet in flight
 constexpr int kSpMask = 0xff;
-constexpr int kShadeFlag = 1 << 30;   // the finished packet goes to Q_SHADE (it had shadow rays or its continuation hit something), not Q_GEN
+// The continuation's nearest hit is a TRIANGLE (set by the leaf pass that writes such a hit; the brute-force lists at a ray's
+// start leave it clear): the finished packet goes to Q_SHADE, whose batches run the mesh materials -- on the benchmark scene the
+// Disney program, ~3,000 vector instructions.  Every other finished packet (continuation missed, hit a light quad or another
+// analytic primitive, or there was no continuation) goes to Q_GEN: its visit folds the shadow results, runs miss / the
+// analytic primitive's program and, where the sample ended, takes the next work item in the same visit.  Until round 4 every
+// packet with shadow rays went to Q_SHADE: its batches then ran the Disney code with 34 of 64 lanes (profiles/r04_lane_census.txt),
+// and a sample that ended on a miss needed a second visit for its new work item.
+constexpr int kShadeFlag = 1 << 30;
 constexpr int kShadowRay = 1 << 29;   // the ray in flight is a shadow ray (MinimalOptiX.h:48 RAY_TYPE_SHADOW)
 constexpr int kHitValid = 1 << 28;    // SlotCold::hit holds the continuation's nearest hit so far
 constexpr int kCurShift = 8;          // bits 8-9: index of the ray in flight within the packet (shadow rays first)
@@ -233,7 +240,7 @@ struct SlotSink {
     if (axp >= 0) {
       const int ax = (axp >> (kSlotBits * j)) & kSlotMask;
       nodeA[ax] = mk4(ps->o.x, ps->o.y, ps->o.z, tmax); nodeB[ax] = mk4(d.x, d.y, d.z, i2f(root));
-      stack[ax][0] = kAuxSlot | kShadowRay | kShadeFlag | (1 << kNShShift) | aux_parent_bits(slot);      // a packet of one shadow ray
+      stack[ax][0] = kAuxSlot | kShadowRay | (1 << kNShShift) | aux_parent_bits(slot);      // a packet of one shadow ray
     } else if (j == 0) { nodeA[slot] = mk4(ps->o.x, ps->o.y, ps->o.z, tmax); nodeB[slot] = mk4(d.x, d.y, d.z, i2f(root)); }   // ps->o: the hit point
     else slot_store(&cw->ray[j - 1], mk4(d.x, d.y, d.z, tmax));
   }
@@ -324,10 +331,12 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
   // A borrowed slot's shadow ray is done (its attenuation is in its flag word / att row, read by the path slot's next
   // visit).  Returns the path slot if this was the last one out and the path slot's own ray is done as well (the caller
   // pushes it to Q_SHADE), else -1.
-  auto aux_done = [&](int fl) -> int {
+  auto aux_done = [&](int fl, int& dest) -> int {
     const int parent = aux_parent(fl);
     const int old = atomicSub(&W.stack[parent][0], 1 << kJoinShift);
-    return (old & kJoinMask) == ((1 << kJoinShift) | kArrived) ? parent : -1;
+    const bool last = (old & kJoinMask) == ((1 << kJoinShift) | kArrived);
+    dest = last ? ((old & kShadeFlag) ? Q_SHADE : Q_GEN) : DEST_NONE;      // kArrived in `old`: the path slot's own flags are final
+    return last ? parent : -1;
   };
 
   // ---- start-up: every slot in use needs a work item ----
@@ -515,7 +524,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           if (__builtin_expect(tv.node == kTravDone && (nfl & (kHasAux | kAuxSlot)) != 0, 0)) {      // rare: deep paths only
             if (nfl & kAuxSlot) {
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the att row written above is read by the path slot's visit
-              pendSlot = aux_done(nfl); pendDest = pendSlot >= 0 ? Q_SHADE : DEST_NONE;
+              pendSlot = aux_done(nfl, pendDest);
             } else if (arrive_parks(slot)) pendDest = DEST_NONE;
           }
         }
@@ -688,7 +697,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         }
         if (pk.hasScale) { slot_store(&cw->bsc, mk4(pk.bscale.x, pk.bscale.y, pk.bscale.z, pk.binv)); PT_ROWS(1, 1); }
         W.stack[slot][0] = (nOwnSh << kNShShift) | ((max(nRays, 1) - 1) << kNRayShift) | (nOwnSh > 0 ? kShadowRay : 0) | (pk.nShadow << kPendShift) |
-                           (hitNow ? kHitValid : 0) | ((pk.nShadow > 0 || hitNow) ? kShadeFlag : 0) | (pk.hasScale ? kHasScale : 0) |
+                           (hitNow ? kHitValid : 0) | (pk.hasScale ? kHasScale : 0) |
                            (useAux ? kHasAux : 0);
         pendDest = sc.rootRef >= 0 ? Q_NODE : Q_LEAF;
         if (useAux) {
@@ -730,7 +739,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           if (__builtin_expect(nodeOut == kTravDone && (nsFlag & (kHasAux | kAuxSlot)) != 0, 0)) {     // rare: deep paths only
             if (nsFlag & kAuxSlot) {
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // att rows written by this wave's last leaf pass
-              pushSlot = aux_done(nsFlag); dest = pushSlot >= 0 ? Q_SHADE : DEST_NONE;
+              pushSlot = aux_done(nsFlag, dest);
             } else if (arrive_parks(ns)) dest = DEST_NONE;
           }
         }
@@ -826,6 +835,10 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
                             wave_sum(ct.nodeFetches), wave_sum(ct.triTests), wave_sum(ct.closestHits), wave_sum(ct.lightLoads),
                             wave_sum(ct.analyticTests) };
     const uint32_t rw[4] = { wave_sum(rows[0]), wave_sum(rows[1]), wave_sum(rows[2]), wave_sum(rows[3]) };
+    for (int i = 0; i < kCensusRegions; i++) {
+      const uint32_t cl = wave_sum(ct.censusLanes[i]), cw = wave_sum(ct.censusWaves[i]);
+      if (lane == 0 && cw != 0u) { atomicAdd(&c[816 + i], (unsigned long long)cl); atomicAdd(&c[816 + kCensusRegions + i], (unsigned long long)cw); }
+    }
     if (lane == 0) {
       for (int i = 0; i < 9; i++) atomicAdd(&c[i], (unsigned long long)v[i]);
       atomicAdd(&c[9], (unsigned long long)nodeSteps + leafPasses);

@@ -66,7 +66,7 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
   for (int li = 0; li < sc.nLights; li++) {                 // li is uniform across the wave: the record is a scalar load
     const DevLight ltv = load_uniform(sc.lights + li);
     const DevLight* lt = &ltv;
-    cnt<CNT>(ct.lightLoads);
+    cnt<CNT>(ct.lightLoads); census<CNT>(ct, CR_LIGHT_DRAW);
     v3 pointOnLight, normalOnLight;
     if (lt->shape == LIGHT_SPHERE) {
       pointOnLight = lt->position + rand_in_unit_sphere(ps.seed) * lt->radius;
@@ -80,6 +80,7 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
     const float lightDst = length(L);
     L = normalize(L);
     if (dot(L, ps.N) > 0.f && dot(L, normalOnLight) < 0.f && pk.nShadow < kPacketShadows) {
+      census<CNT>(ct, li < 2 ? CR_LIGHT0 + li : CR_LIGHT2);
       const v3 H = normalize(L + ps.V);
       const float lightPdf = lightDst * lightDst / lt->area / dot(normalOnLight, -L);
       const float pdf = disney_pdf<FAST>(m, ps.N, L, H);
@@ -95,8 +96,10 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
     }
   }
   v3 L, H;
+  census<CNT>(ct, CR_BOUNCE_SAMPLE);
   disney_sample(ps.seed, m, onb, ps.V, L, H);
   if (dot(ps.N, L) > 0.0f && dot(ps.N, ps.V) > 0.0f) {
+    census<CNT>(ct, CR_BOUNCE_EVAL);
     const float pdf = disney_pdf<FAST>(m, ps.N, L, H);
     const v3 brdf = disney_eval<FAST>(m, Cdlin, Cspec0, Csheen, ps.N, dv, L, H);
     const uint32_t childSeed = fork_seed(ps.seed, ps.depth + 1);
@@ -115,11 +118,13 @@ PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Coun
 template <bool CNT, bool FAST = false, class Sink = PacketSink>
 PT_HD void on_result_packet(const SceneView& sc, PathState& ps, Packet& pk, const Trav& tv, const v3 att[kPacketShadows], Counters& ct,
                             const Sink& sink) {
+  census<CNT>(ct, CR_RESULT);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
   for (int i = 0; i < kPacketShadows; i++) {                      // Material.cu:193-201, light order
     if (i < pk.nShadow && pk.pendInv[i] != 0.f && length_is_nonzero(att[i])) {
+      census<CNT>(ct, CR_SHADOW_FOLD);
       const v3 c = (pk.pendW[i] * att[i]) * pk.pendInv[i];
       ps.rad = ps.rad + ps.thr * c;
     }

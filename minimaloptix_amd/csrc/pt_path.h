@@ -25,8 +25,23 @@ enum { RK_RADIANCE = 0, RK_SHADOW = 1 };   // MinimalOptiX.h:48 RayType
 struct Counters {
   uint32_t samples, primaryRays, bounceRays, shadowRays;
   uint32_t nodeFetches, triTests, closestHits, lightLoads, analyticTests;
+  // counting build only: lanes / waves that entered each divergent region of the passes (census<> below; the table is
+  // printed under MOPTIX_DEBUG and committed as profiles/r04_lane_census.txt)
+  uint32_t censusLanes[kCensusRegions], censusWaves[kCensusRegions];
 };
 template <bool CNT> PT_HD void cnt(uint32_t& c, uint32_t n = 1) { if (CNT) c += n; }
+enum { CR_RESULT = 0, CR_MISS, CR_HIT, CR_LIGHT, CR_DEPTHCAP, CR_LAMBERT, CR_METAL, CR_GLASS, CR_DISNEY_GLASS, CR_DISNEY, CR_LIGHT0, CR_LIGHT1,
+       CR_LIGHT2, CR_BOUNCE_EVAL, CR_GEN, CR_TRI0, CR_TRI1, CR_TRI2, CR_TRI3, CR_TRI_HIT, CR_SHADOW_FOLD, CR_LIGHT_DRAW, CR_BOUNCE_SAMPLE };
+// one call at the top of a region: every lane that is active here counts itself, the lowest of them counts the wave
+template <bool CNT> PT_HD void census(Counters& ct, int region) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (CNT) {
+    const unsigned long long m = __ballot(1);
+    ct.censusLanes[region]++;
+    if (__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) == 0) ct.censusWaves[region]++;
+  }
+#endif
+}
 
 struct Trav {
   int node;        // current node/leaf reference; kTravDone when the ray is finished
@@ -354,9 +369,10 @@ PT_HD void trav_leaf_step_fetched(const SceneView& sc, const PathState& ps, Trav
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (base + j < count && !terminated) {
-          cnt<CNT>(ct.triTests);
+          cnt<CNT>(ct.triTests); census<CNT>(ct, CR_TRI0 + j);
           v3 n; float t, be, ga;
           if (tri_test(ps.o, ps.d, ps.tmin, tmaxTest, ch.p0[j], ch.e0[j], ch.e1[j], n, t, be, ga)) {   // meshIntersect, Geometry.cu:121-160
+            census<CNT>(ct, CR_TRI_HIT);
             if (ps.kind == RK_RADIANCE) {
               if (potential(t, triBase + ch.prim[j], ps.tmin, tv.tbest, tv.bestPrim)) {
                 tv.tbest = t; tv.bestPrim = triBase + ch.prim[j]; tv.bestTri = first + base + j; tv.beta = be; tv.gamma = ga;
@@ -407,7 +423,7 @@ PT_HD void begin_sample(const SceneView& sc, PathState& ps, int launchSeed, Coun
   ps.d = normalize((((sc.cam.scrLowerLeftCorner + sc.cam.horizontal * xyx) + sc.cam.vertical * xyy) - sc.cam.origin) - offs);
   ps.tmin = sc.epsT; ps.tmax = kRtDefaultMax; ps.kind = RK_RADIANCE;
   ps.mode = M_TRACE;
-  cnt<CNT>(ct.samples); cnt<CNT>(ct.primaryRays);
+  cnt<CNT>(ct.samples); cnt<CNT>(ct.primaryRays); census<CNT>(ct, CR_GEN);
 }
 
 // Camera.cu:39: clamp the sample.  The add into accuBuffer (Camera.cu:41) is done by the
@@ -507,15 +523,17 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
     return;
   }
   if (tv.bestPrim < 0) {                                        // staticMiss, miss.cu:10-12
+    census<CNT>(ct, CR_MISS);
     ps.rad = ps.rad + ps.thr * sc.bg;
     end_sample(ps);
     return;
   }
-  cnt<CNT>(ct.closestHits);
+  cnt<CNT>(ct.closestHits); census<CNT>(ct, CR_HIT);
   HitAttr h;
   hit_attributes(sc, ps, tv, h);
   const DevMaterial m = load_const(sc.mats + h.mat);
   if (m.kind == MAT_LIGHT) {                                    // light, Material.cu:238-240
+    census<CNT>(ct, CR_LIGHT);
     ps.rad = ps.rad + ps.thr * m.emission;
     end_sample(ps);
     return;
@@ -523,9 +541,10 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
   // Material.cu:29,50,73,119: depth cap -> absorbColor (0,0,0).  The second half of that test,
   // length(payload.color) < rayMinIntensity, is dead in the reference: every payload starts
   // at (1,1,1).
-  if (ps.depth > sc.maxDepth) { end_sample(ps); return; }
+  if (ps.depth > sc.maxDepth) { census<CNT>(ct, CR_DEPTHCAP); end_sample(ps); return; }
 
   if (m.kind == MAT_LAMBERTIAN) {                               // Material.cu:28-43
+    census<CNT>(ct, CR_LAMBERT);
     const v3 no = ray_at(ps.o, ps.d, tv.tbest);
     const v3 nd = normalize(h.geoNormal + rand_in_unit_sphere(ps.seed));
     const uint32_t childSeed = fork_seed(ps.seed, ps.depth + 1);
@@ -533,6 +552,7 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
     cnt<CNT>(ct.bounceRays);
     bounce(sc, ps, no, nd, childSeed);
   } else if (m.kind == MAT_METAL) {                             // Material.cu:49-66
+    census<CNT>(ct, CR_METAL);
     const v3 no = ray_at(ps.o, ps.d, tv.tbest);
     const v3 nd = normalize(reflect(ps.d, h.geoNormal) + rand_in_unit_sphere(ps.seed) * m.fuzz);
     const uint32_t childSeed = fork_seed(ps.seed, ps.depth + 1);
@@ -540,6 +560,7 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
     cnt<CNT>(ct.bounceRays);
     bounce(sc, ps, no, nd, childSeed);
   } else if (m.kind == MAT_GLASS) {                             // Material.cu:72-110
+    census<CNT>(ct, CR_GLASS);
     glass_body<CNT>(sc, ps, m.refIdx, m.albedo, h, ct);
   } else {                                                      // disney, Material.cu:118-223
     v3 baseColor = m.color;
@@ -547,7 +568,8 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
       baseColor = xyz(tex2d(sc.textures[m.albedoTex - 1], h.texu, h.texv));
       ps.cdlin = srgb2lin(baseColor);
     }
-    if (m.brdfType == BRDF_GLASS) { glass_body<CNT>(sc, ps, 1.45f, baseColor, h, ct); return; }
+    if (m.brdfType == BRDF_GLASS) { census<CNT>(ct, CR_DISNEY_GLASS); glass_body<CNT>(sc, ps, 1.45f, baseColor, h, ct); return; }
+    census<CNT>(ct, CR_DISNEY);
     ps.N = faceforward(h.shadingNormal, -ps.d, h.geoNormal);
     ps.V = -ps.d;
     ps.mat = h.mat;

@@ -45,6 +45,7 @@ template <class T> PT_HD T load_uniform(const T* p) { return load_const(p); }   
 PT_HD int make_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
 PT_HD int leaf_first(int ref) { return (~ref) >> 3; }
 PT_HD int leaf_count(int ref) { return ((~ref) & 7) + 1; }
+constexpr int kCensusRegions = 24;     // counting build: divergent regions of the passes whose lanes are counted (pt_path.h census<>)
 constexpr int kTravDone = 0x7fffffff;   // traversal finished sentinel in Trav::node
 constexpr int kEmptyRef = 0x7ffffffe;   // "no triangles" root
 
