@@ -45,12 +45,18 @@ struct LaneStack {
   }
   __device__ __forceinline__ bool roomy(int sp) const { return sp + 3 <= kLdsStack; }
   __device__ __forceinline__ void store_fast(int sp, int v) { lds[sp * 64] = v; }
+  static constexpr bool kFlat = false;      // pt_path.h node_step_nearfar: this stack takes the branched tail
+  __device__ __forceinline__ bool fits_fast(int, int) const { return false; }
+  __device__ __forceinline__ int peek_fast(int) const { return 0; }
 };
 struct NoStack {
   __device__ __forceinline__ void store(int, int) {}
   __device__ __forceinline__ int load(int) const { return kTravDone; }
   __device__ __forceinline__ bool roomy(int) const { return false; }
   __device__ __forceinline__ void store_fast(int, int) {}
+  static constexpr bool kFlat = false;      // pt_path.h node_step_nearfar: this stack takes the branched tail
+  __device__ __forceinline__ bool fits_fast(int, int) const { return false; }
+  __device__ __forceinline__ int peek_fast(int) const { return 0; }
 };
 
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }

@@ -238,7 +238,7 @@ int read_stats(moptix_context c, moptix_stats* stats) {
       static const char* names[kCensusRegions] = { "result visit (on_result_packet)", "  miss", "  closest hit (hit_attributes + material)", "    light material",
         "    depth cap", "    lambertian", "    metal", "    glass", "    disney GLASS", "    disney (on_lights_packet)", "      light 0 faces: pdf + eval", "      light 1 faces: pdf + eval",
         "      light 2 faces: pdf + eval", "      bounce: pdf + eval", "new work item (begin_sample)", "leaf pass: triangle 0 tested", "leaf pass: triangle 1 tested",
-        "leaf pass: triangle 2 tested", "leaf pass: triangle 3 tested", "  triangle hit accepted by tri_test", "  shadow result folded", "      light draw (per light)", "      bounce: disney_sample", "" };
+        "leaf pass: triangle 2 tested", "leaf pass: triangle 3 tested", "  triangle hit accepted by tri_test", "  shadow result folded", "      light draw (per light)", "      bounce: disney_sample", "node step: branched tail (stack nearly full)" };
       fprintf(stderr, "[moptix] lane census: region | waves that entered | lanes that entered | lanes per wave (of 64)\n");
       for (int i = 0; i < kCensusRegions; i++)
         if (h[816 + kCensusRegions + i]) fprintf(stderr, "[moptix]   %-46s %12llu %14llu %6.1f\n", names[i], h[816 + kCensusRegions + i], h[816 + i], (double)h[816 + i] / (double)h[816 + kCensusRegions + i]);

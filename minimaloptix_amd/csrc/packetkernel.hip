@@ -193,6 +193,11 @@ struct SlotStack {
   }
   __device__ __forceinline__ bool roomy(int sp) const { return sp + 3 <= kStackN; }     // three pushes stay in LDS
   __device__ __forceinline__ void store_fast(int sp, int v) { lds[sp] = v; }
+  // pt_path.h node_step_nearfar's branch-free tail: m pushes on top of sp entries stay in LDS and entry sp exists (the dead
+  // store of a step that enters nothing lands there); the entry a pop would take (sp - 1; for sp = 0 the slot's flag word, unused)
+  static constexpr bool kFlat = true;
+  __device__ __forceinline__ bool fits_fast(int sp, int m) const { return sp + m <= kStackN && sp < kStackN; }
+  __device__ __forceinline__ int peek_fast(int sp) const { return lds[min(sp, kStackN) - 1]; }
 };
 
 __device__ __forceinline__ float node_inv(float d) {      // slab_inv (pt_path.h) with the hardware reciprocal

@@ -31,7 +31,7 @@ struct Counters {
 };
 template <bool CNT> PT_HD void cnt(uint32_t& c, uint32_t n = 1) { if (CNT) c += n; }
 enum { CR_RESULT = 0, CR_MISS, CR_HIT, CR_LIGHT, CR_DEPTHCAP, CR_LAMBERT, CR_METAL, CR_GLASS, CR_DISNEY_GLASS, CR_DISNEY, CR_LIGHT0, CR_LIGHT1,
-       CR_LIGHT2, CR_BOUNCE_EVAL, CR_GEN, CR_TRI0, CR_TRI1, CR_TRI2, CR_TRI3, CR_TRI_HIT, CR_SHADOW_FOLD, CR_LIGHT_DRAW, CR_BOUNCE_SAMPLE };
+       CR_LIGHT2, CR_BOUNCE_EVAL, CR_GEN, CR_TRI0, CR_TRI1, CR_TRI2, CR_TRI3, CR_TRI_HIT, CR_SHADOW_FOLD, CR_LIGHT_DRAW, CR_BOUNCE_SAMPLE, CR_NODE_BRANCHED };
 // one call at the top of a region: every lane that is active here counts itself, the lowest of them counts the wave
 template <bool CNT> PT_HD void census(Counters& ct, int region) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -266,7 +266,7 @@ struct ChildKey {
 // the plane of child k's box the ray meets first / last, per axis.  needTest[k]: child k may be an unused slot.
 template <bool CNT, class Stack>
 PT_HD void node_step_nearfar(const PathState& ps, Trav& tv, Stack& st, Counters& ct, const float nx[4], const float fx[4], const float ny[4],
-                             const float fy[4], const float nz[4], const float fz[4], int r0, int r1, int r2, int r3) {
+                             const float fy[4], const float nz[4], const float fz[4], int r0, int r1, int r2, int r3, int top) {
   const int r[4] = { r0, r1, r2, r3 };
   cnt<CNT>(ct.nodeFetches);
   const float kFar = 3.0e38f;
@@ -282,6 +282,24 @@ PT_HD void node_step_nearfar(const PathState& ps, Trav& tv, Stack& st, Counters&
   }
   ChildKey::order(k[0], k[1]); ChildKey::order(k[2], k[3]); ChildKey::order(k[0], k[2]);
   ChildKey::order(k[1], k[3]); ChildKey::order(k[1], k[2]);
+  if constexpr (Stack::kFlat) {
+    // The step's tail without a branch (the common case): sorted keys are hits first, so with h_j = "child j of the order is
+    // entered" the m = h1 + h2 + h3 pushes are k[m] .. k[1], farthest first.  All three stores are issued: store i goes to entry
+    // sp + min(i, m - 1) and carries what belongs there (the stores past the last real one repeat it; with m = 0 they put
+    // a dead value just above the top), and the entry below the top was read before the node's record arrived (`top`): a lane
+    // that enters no child takes it.  ~60 scalar instructions (exec masks, skips) per step in the branched form.
+    const bool h0 = k[0].t() < kFar, h1 = k[1].t() < kFar, h2 = k[2].t() < kFar, h3 = k[3].t() < kFar;
+    const int m = (int)h1 + (int)h2 + (int)h3;
+    if (__builtin_expect(st.fits_fast(tv.sp, m), 1)) {
+      const int r1 = k[1].ref(), r2 = k[2].ref(), r3 = k[3].ref();
+      const int p1 = tv.sp + (int)h2, p2 = p1 + (int)h3;
+      st.store_fast(tv.sp, h3 ? r3 : (h2 ? r2 : r1)); st.store_fast(p1, h3 ? r2 : r1); st.store_fast(p2, r1);
+      tv.node = h0 ? k[0].ref() : (tv.sp > 0 ? top : kTravDone);
+      tv.sp = h0 ? p2 + (int)h1 : (tv.sp > 0 ? tv.sp - 1 : 0);
+      return;
+    }
+    census<CNT>(ct, CR_NODE_BRANCHED);
+  }
   if (k[0].t() < kFar) {
     // one test for the step instead of one per push: do three more entries fit the stack's fast part?
     if (PT_STACK_ROOMY && st.roomy(tv.sp)) {
@@ -315,6 +333,8 @@ PT_HD void planes4q(uint32_t w, float step, float base, float out[4]) {
 template <bool CNT, bool N64 = false, class Stack>
 PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
   float nx[4], fx[4], ny[4], fy[4], nz[4], fz[4];
+  int top = kTravDone;
+  if constexpr (Stack::kFlat) top = st.peek_fast(tv.sp);      // the entry below the top, requested together with the node
   if constexpr (N64) {
     const Node64 n = load_const(sc.nodes64 + tv.node);
     const float sx = n.sx * tv.inv.x, sy = n.sy * tv.inv.y, sz = n.sz * tv.inv.z;
@@ -323,7 +343,7 @@ PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, St
     planes4q(bx ? n.q[3] : n.q[0], sx, cx, nx); planes4q(bx ? n.q[0] : n.q[3], sx, cx, fx);
     planes4q(by ? n.q[4] : n.q[1], sy, cy, ny); planes4q(by ? n.q[1] : n.q[4], sy, cy, fy);
     planes4q(bz ? n.q[5] : n.q[2], sz, cz, nz); planes4q(bz ? n.q[2] : n.q[5], sz, cz, fz);
-    node_step_nearfar<CNT>(ps, tv, st, ct, nx, fx, ny, fy, nz, fz, n.ref[0], n.ref[1], n.ref[2], n.ref[3]);
+    node_step_nearfar<CNT>(ps, tv, st, ct, nx, fx, ny, fy, nz, fz, n.ref[0], n.ref[1], n.ref[2], n.ref[3], top);
   } else {
     const Node128 n = load_const(sc.nodes + tv.node);
     float a[4], b[4];
@@ -333,7 +353,7 @@ PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, St
     for (int c = 0; c < 4; c++) { ny[c] = fminf_(a[c], b[c]); fy[c] = fmaxf_(a[c], b[c]); }
     planes4(n.loz, tv.inv.z, tv.noi.z, a); planes4(n.hiz, tv.inv.z, tv.noi.z, b);
     for (int c = 0; c < 4; c++) { nz[c] = fminf_(a[c], b[c]); fz[c] = fmaxf_(a[c], b[c]); }
-    node_step_nearfar<CNT>(ps, tv, st, ct, nx, fx, ny, fy, nz, fz, n.ref[0], n.ref[1], n.ref[2], n.ref[3]);
+    node_step_nearfar<CNT>(ps, tv, st, ct, nx, fx, ny, fy, nz, fz, n.ref[0], n.ref[1], n.ref[2], n.ref[3], top);
   }
 }
 

@@ -147,6 +147,9 @@ struct SlotStack {
   }
   __device__ __forceinline__ bool roomy(int sp) const { return sp + 3 <= kStackN; }     // three pushes stay in LDS
   __device__ __forceinline__ void store_fast(int sp, int v) { lds[sp] = v; }
+  static constexpr bool kFlat = false;      // pt_path.h node_step_nearfar: this stack takes the branched tail
+  __device__ __forceinline__ bool fits_fast(int, int) const { return false; }
+  __device__ __forceinline__ int peek_fast(int) const { return 0; }
 };
 
 __device__ __forceinline__ float node_inv(float d) {      // slab_inv (pt_path.h) with the hardware reciprocal

@@ -262,6 +262,9 @@ struct LocalStack {
   inline int load(int sp) const { return data[sp]; }
   inline bool roomy(int) const { return true; }
   inline void store_fast(int sp, int v) { data[sp] = v; }
+  static constexpr bool kFlat = false;      // pt_path.h node_step_nearfar: this stack takes the branched tail
+  inline bool fits_fast(int, int) const { return false; }
+  inline int peek_fast(int) const { return 0; }
 };
 
 static inline void host_trav_step(const SceneView& sc, const PathState& ps, Trav& tv, LocalStack& st, Counters& ct) {
