@@ -29,9 +29,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 NODE_BYTES = 64             # the node record the packet kernel fetches on coffee (csrc/pt_types.h Node64; get_option "node_format_used" says which)
-VALU_ISSUE_PEAK_G = 256 * 4 * 2.4 / 4.0     # G wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 vector instruction per SIMD every 4 clocks at 2.4 GHz (same guide)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
 GATHER_CEILING_FILE = os.path.join("profiles", "r03_gather_ceiling.txt")    # output of tools/micro/gather on MI355X
+VALU_CEILING_FILE = os.path.join("profiles", "r04_valu_ceiling.txt")        # output of tools/micro/valu_issue on MI355X
+KERNEL_WAVES_PER_SIMD = 3   # what the trace kernel's 168 registers and 53 KB of LDS allow (csrc/packetkernel.hip)
 
 
 def source_hash(repo):
@@ -76,6 +77,27 @@ def gather_ceilings(repo):
     return best if "l2_128" in best and "l2_64" in best else None
 
 
+def valu_ceilings(repo):
+    """Measured issue rates of the vector ALUs (tools/micro/valu_issue.hip on MI355X; the committed output is the evidence):
+    {instruction: {waves per SIMD: G wave-instructions/s, chip-wide}}.  None when the file is missing."""
+    out = {}
+    try:
+        for l in open(os.path.join(repo, VALU_CEILING_FILE)):
+            f = l.split()
+            if len(f) == 6 and not l.startswith("#"):
+                out.setdefault(f[0], {})[int(f[1])] = float(f[3])
+    except (OSError, ValueError):
+        return None
+    return out if "v_fma_f32" in out and "v_min_f32" in out else None
+
+
+def fp32_vector_peak_tflops(repo, waves_per_simd=8):
+    """The FP32 vector peak as measured: v_fma_f32 wave-instructions/s x 64 lanes x 2 flop.  BASELINE config 2 (brute-force
+    spheres) is priced against this number -- the same measurement the trace kernel's instruction rate is priced against."""
+    c = valu_ceilings(repo)
+    return None if not c else c["v_fma_f32"][waves_per_simd] * 128e-3
+
+
 def cpu_baseline(width, height, target_s):
     """north_star / BASELINE.md section 2: "a CPU build of the same megakernel" -- the per-lane path code of
     minimaloptix_amd/csrc/pt_path.h and the same LBVH (tests/hostsim, test infrastructure; kind "port": the reference
@@ -112,50 +134,49 @@ def read_traffic(repo):
     return t
 
 
-def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per_ray, rays, reduce_ms, kernel, traffic, ceil, node_bytes=NODE_BYTES):
-    """The dominant kernel against the roof that binds it.
+def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per_ray, rays, reduce_ms, kernel, traffic, ceil, node_bytes=NODE_BYTES, vceil=None):
+    """The dominant kernel against its roofs.
 
-    What binds it: the issue rate of the vector ALUs at the three waves per SIMD the kernel's
-    registers and LDS allow.  Evidence: the counters (vector pipes busy 0.7 of all cycles at 0.57 of the lanes, the L1
-    address unit well below that, fabric a quarter of HBM's peak); halving the node record (7 -> 4 look-ups per node)
-    moved the frame by 1.6 %; the traversal-only build of the kernel steps the same 68 G nodes/s with either record;
-    every instruction added to the node step shows up at 3-4 clocks.  So `achieved` / `peak` / `frac` are wave-level
-    vector instructions per second -- per launch from the committed PMC pass of THIS device code (profiles/traffic.json,
-    SQ_INSTS_VALU), divided by the launch duration measured live -- against one instruction per SIMD per 4 clocks.
-    Without a PMC pass for this device code the block falls back to the memory side below.
+    Head of the block (the contract's form): SURVEY 8(d)'s ALGORITHMIC bytes per launch / the launch duration measured here,
+    against the HBM peak.  Those bytes are served by the XCDs' L2s and the Infinity Cache (what really crossed the fabric is
+    `traffic` / `hbm_frac`, from the PMC passes), so the fraction says how much traversal work per second the kernel does in
+    the survey's currency, not that HBM is 0.9 busy.
 
-    The memory side (SURVEY 8d's algorithmic bytes) stays as named fields: the traversal's bytes are served by the XCDs'
-    L2s and the Infinity Cache, every fetch depends on the one before it, and the chip's rate for such per-lane gathers
-    of 64-byte records from an L2-resident table is profiles/r03_gather_ceiling.txt (`gather_*`); HBM enters as
-    `hbm_frac` (bytes that really crossed the fabric, PMC) and as the SURVEY figure `algorithmic_frac_of_hbm`."""
+    `valu_issue`: what the counters say binds the kernel -- the issue rate of the vector ALUs at the three waves per SIMD its
+    registers and LDS allow.  achieved = SQ_INSTS_VALU per launch (PMC pass of THIS device code, profiles/traffic.json) / the
+    launch duration measured here; peak = the chip's measured rate for independent v_fma_f32 at three waves per SIMD
+    (profiles/r04_valu_ceiling.txt, tools/micro/valu_issue.hip; v_min / v_max / v_cvt / v_cmp / v_cndmask issue at about
+    half of it, `peak_half_rate_class`); useful_lane_frac = frac x the share of lanes active in an issued instruction.
+    `live_fields` / `replayed_fields` say which numbers were measured in this run and which come from the committed passes."""
     launch_s = launch_ms * 1e-3
     fabric_gb = traffic.get("traffic_GB_per_launch") if traffic else None
     gpeak = ceil["l2_%d" % node_bytes] if ceil else None
-    valu = (traffic.get("SQ") or {}).get("SQ_INSTS_VALU") if traffic else None
-    lanes = None
-    if traffic and (traffic.get("SQ") or {}).get("SQ_THREAD_CYCLES_VALU") and traffic["SQ"].get("SQ_ACTIVE_INST_VALU"):
-        lanes = round(traffic["SQ"]["SQ_THREAD_CYCLES_VALU"] / (64.0 * traffic["SQ"]["SQ_ACTIVE_INST_VALU"]), 4)
-    if valu:
+    sq = (traffic.get("SQ") or {}) if traffic else {}
+    valu = sq.get("SQ_INSTS_VALU")
+    lanes = round(sq["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"]), 4) if sq.get("SQ_THREAD_CYCLES_VALU") and sq.get("SQ_ACTIVE_INST_VALU") else None
+    head = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+            "traffic": fabric_gb,
+            "achieved_source": "SURVEY 8(d) algorithmic bytes of one launch (counting launch of this run: %d B per node fetch, 48 per triangle test, 108 per closest "
+                               "hit, 72 per light record, 24 per pixel) / mean launch duration of the timed region (HIP events on the launch stream)" % node_bytes,
+            "kernel": kernel, "node_bytes": int(node_bytes), "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
+            "algorithmic_bytes_per_launch": int(bytes_per_launch), "bytes_per_ray": round(bytes_per_ray, 1)}
+    vi = None
+    if valu and vceil:
         ach = valu / launch_s / 1e9
-        head = {"bound": "valu_issue", "achieved": round(ach, 1), "peak": round(VALU_ISSUE_PEAK_G, 1), "unit": "Ginstr/s",
-                "frac": round(ach / VALU_ISSUE_PEAK_G, 4), "traffic": fabric_gb,
-                "peak_source": "256 CUs x 4 SIMDs x 2.4 GHz / 4 clocks per wave64 vector instruction; achieved = SQ_INSTS_VALU per launch "
-                               "(profiles/traffic.json, PMC pass of this device code) / launch duration measured here"}
-    else:
-        head = {"bound": "l2_gather_latency", "achieved": round(achieved_gbs, 1), "peak": round(gpeak, 1) if gpeak else None, "unit": "GB/s",
-                "frac": round(achieved_gbs / gpeak, 4) if gpeak else None, "traffic": fabric_gb,
-                "peak_source": GATHER_CEILING_FILE + " (no PMC pass for this device code: memory side only)"}
+        peak = vceil["v_fma_f32"][KERNEL_WAVES_PER_SIMD]
+        half = vceil["v_min_f32"][KERNEL_WAVES_PER_SIMD]
+        vi = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s", "frac": round(ach / peak, 4),
+              "peak_source": "%s: v_fma_f32, %d waves per SIMD, 256 CUs (measured, includes the clock the chip holds under that load)" % (VALU_CEILING_FILE, KERNEL_WAVES_PER_SIMD),
+              "peak_half_rate_class": round(half, 1), "frac_of_half_rate_class": round(ach / half, 4),
+              "peak_best_occupancy": round(max(vceil["v_fma_f32"].values()), 1),
+              "instructions_per_ray": round(valu / max(1, rays), 2), "lane_utilisation": lanes,
+              "useful_lane_frac": round(ach / peak * lanes, 4) if lanes else None,
+              "valu_active_frac": traffic.get("valu_active_frac")}
+    head["valu_issue"] = vi
     head.update({
-        "valu_instructions_per_ray": round(valu / max(1, rays), 2) if valu else None,      # wave-level instructions per ray traced
-        "valu_lane_utilisation": lanes,
-        "kernel": kernel, "node_bytes": int(node_bytes), "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
-        "algorithmic_bytes_per_launch": int(bytes_per_launch), "bytes_per_ray": round(bytes_per_ray, 1),
-        "algorithmic_GBps": round(achieved_gbs, 1), "algorithmic_frac_of_hbm": round(achieved_gbs / HBM_PEAK_GBS, 4),
         "gather_peak_GBps": round(gpeak, 1) if gpeak else None, "gather_frac": round(achieved_gbs / gpeak, 4) if gpeak else None,
         "gather_peak_source": GATHER_CEILING_FILE + " (tools/micro/gather.hip: dependent per-lane gathers of %d-B records, 3.1 MB table, best over occupancies)" % node_bytes,
-        "gather_peak_at_kernel_occupancy_GBps": round(ceil["l2_%d_at_12_waves" % node_bytes], 1) if ceil and ("l2_%d_at_12_waves" % node_bytes) in ceil else None,
         "infinity_cache_gather_GBps": round(ceil["ic_%d" % node_bytes], 1) if ceil and ("ic_%d" % node_bytes) in ceil else None,
-        "hbm_peak_GBps": HBM_PEAK_GBS,
         "hbm_frac": round(fabric_gb / launch_s / HBM_PEAK_GBS, 4) if fabric_gb else None,
         # FETCH_SIZE tallies 64 B per fabric read request; a request of this kernel's gathers fills a 128-byte line (calibrated with
         # the gather micro-benchmark, profiles/r03_fetch_size_calibration.txt): upper figure with the read side doubled
@@ -167,8 +188,13 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
         # the CU's vector-memory address path (one L1 tag look-up per clock); PMC
         "l1_address_unit_busy_frac": traffic.get("ta_busy_frac") if traffic else None,
         "l1_lookups_per_cu_clock": traffic.get("l1_lookups_per_cu_clock") if traffic else None,
-        "valu_active_frac": traffic.get("valu_active_frac") if traffic else None,
         "reduce_ms_total": round(reduce_ms, 3),
+        "live_fields": ["achieved", "frac", "launch_ms", "launches_timed", "algorithmic_bytes_per_launch", "bytes_per_ray", "gather_frac", "reduce_ms_total",
+                        "valu_issue.achieved / frac / useful_lane_frac (numerator replayed, launch duration live)"],
+        "replayed_fields": ["traffic", "hbm_frac", "hbm_frac_if_128B_reads", "fabric_GBps", "fabric_bytes_per_ray", "tcc_hit_rate", "l1_address_unit_busy_frac",
+                            "l1_lookups_per_cu_clock", "valu_issue.instructions_per_ray / lane_utilisation / valu_active_frac (profiles/traffic.json, "
+                            "rocprofv3 --pmc passes of this device code: source_hash-gated, null otherwise)", "peaks (profiles/r04_valu_ceiling.txt, "
+                            "profiles/r03_gather_ceiling.txt, HBM spec)"],
     })
     return head
 
@@ -233,6 +259,9 @@ class GpuFrame:
         else:
             self.ctx.set_partition(self.part_rank, self.part_n)
         self.ctx.load(hs)
+        self.build_ms_cold = self.ctx.accel_info().buildMs
+        self.ctx.build_accel("Trbvh" if self.ctx.accel_info().nTriangles else "NoAccel")      # same tree again, code already loaded
+        self.build_ms_warm = self.ctx.accel_info().buildMs
         W, H = a.width, a.height
         self.accum = torch.zeros(H * W * 3, dtype=torch.float32, device=self.device)
         self.ctx.accum_bind(self.accum.data_ptr())
@@ -255,6 +284,7 @@ class GpuFrame:
             self.ctxs.append(ctx2); self.accums.append(accum2)
         self.pending = [False] * len(self.ctxs)
         self.frame_no = 0
+        self.collective_s, self.collectives = 0.0, 0
         # the frame's collective runs behind the C ABI on the context's own RCCL communicator (moptix_gather_tiles /
         # moptix_reduce_frame); MOPTIX_BENCH_FORCE_DIST=1 brings a one-rank communicator up on a 1-GPU box
         self.use_comm = world > 1 or os.environ.get("MOPTIX_BENCH_FORCE_DIST") == "1"
@@ -272,15 +302,23 @@ class GpuFrame:
         st = self.ctx.render_counted(self.seeds)
         px = a.width * a.height if self.sample_split else len(self.D.tile_pixel_indices(a.width, a.height, self.part_rank, self.part_n))
         self.node_bytes = self.ctx.get_option("node_format_used") if self.ctx.get_option("kernel_variant_used") == 4 else 128
+        # the counting launch stamps its own timeline: first wave in -> last wave out, and how much of that came after the last work item
+        self.counted_span_ms = self.ctx.get_option("counted_span_us") * 1e-3
+        self.counted_tail_ms = self.ctx.get_option("counted_tail_us") * 1e-3
         return st.rays, algorithmic_bytes(st, px, self.node_bytes)
 
     def collect(self, j):                                               # the frame's one collective
         a = self.a
         if not self.use_comm:
             return None
+        t0 = time.perf_counter()                                        # the C ABI call returns after its stream has drained
         if self.sample_split:
-            return self.D.reduce_frame(self.accums[j], dst=0, ctx=self.ctxs[j])
-        return self.D.gather_tiles(self.accums[j].view(a.height * a.width, 3), a.width, a.height, self.rank, self.world, dst=0, ctx=self.ctxs[j])
+            r = self.D.reduce_frame(self.accums[j], dst=0, ctx=self.ctxs[j])
+        else:
+            r = self.D.gather_tiles(self.accums[j].view(a.height * a.width, 3), a.width, a.height, self.rank, self.world, dst=0, ctx=self.ctxs[j])
+        self.collective_s += time.perf_counter() - t0
+        self.collectives += 1
+        return r
 
     def _finish(self, j):                                               # frame in context j: wait for it, collect it
         if self.pending[j]:
@@ -311,6 +349,7 @@ class GpuFrame:
     def reset_kernel_time(self):
         for c in self.ctxs:
             c.kernel_time(reset=True)
+        self.collective_s, self.collectives = 0.0, 0
 
     def kernel_times(self):
         kms, n, red = 0.0, 0, 0.0
@@ -345,7 +384,9 @@ class GpuFrame:
         info = self.ctx.accel_info()
         v = self.ctx.get_option("kernel_variant_used")
         return {"kernel_variant": v, "bvh_nodes": int(info.nNodes), "bvh_depth": int(info.treeDepth),
-                "bvh_build_ms": round(float(info.buildMs), 3),
+                "path_slots_per_workgroup": self.ctx.get_option("path_slots") if v == 4 else 512,
+                # the context's first build loads the builder's code objects (~5 ms): both numbers, the warm one is the builder's
+                "bvh_build_ms": round(float(self.build_ms_warm), 3), "bvh_build_ms_first_in_context": round(float(self.build_ms_cold), 3),
                 "kernel": "pt_packetkernel (trace)" if v == 4 else "pt_queuekernel (trace)"}
 
     def parallelism(self):
@@ -430,6 +471,14 @@ def run_rank(a, frame_cls=GpuFrame):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     kms, nlaunch, reduce_ms = fr.kernel_times()
+    # per-rank diagnosis of an N > 1 run (one driver run has to explain itself): each rank's mean trace-kernel ms per frame, the
+    # drain of its counted launch, its collective's wall ms per frame and its ray count, gathered on every rank
+    mine = torch.tensor([kms / max(1, a.steps), getattr(fr, "counted_tail_ms", -1.0), getattr(fr, "counted_span_ms", -1.0),
+                         getattr(fr, "collective_s", 0.0) * 1e3 / max(1, a.steps), float(my_rays)], dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(world)]
+    if use_dist and world > 1:
+        dist.all_gather(per_rank, mine)
+    per_rank = [[float(x) for x in t.tolist()] for t in per_rank]
     fast = None if a.no_fast_leg else fr.fast_leg(total_rays)
 
     if rank == 0:
@@ -440,7 +489,7 @@ def run_rank(a, frame_cls=GpuFrame):
         achieved = my_bytes / passes_per_step / max(launch_ms * 1e-3, 1e-12) / 1e9        # GB/s, rank 0's trace kernel
         d = fr.describe()
         roof = roofline_block(achieved, launch_ms, nlaunch, my_bytes // passes_per_step, my_bytes / max(1, my_rays), my_rays,
-                              reduce_ms, d.pop("kernel"), fr.traffic(), gather_ceilings(REPO), getattr(fr, "node_bytes", NODE_BYTES))
+                              reduce_ms, d.pop("kernel"), fr.traffic(), gather_ceilings(REPO), getattr(fr, "node_bytes", NODE_BYTES), valu_ceilings(REPO))
         out = {
             "metric": "Mrays/s (primary+bounce+shadow rays traced per second, coffee.obj 1920x1080 256spp)",
             "value": round(total_rays / (dt / a.steps) / 1e6, 2), "unit": "Mrays/s",
@@ -451,7 +500,15 @@ def run_rank(a, frame_cls=GpuFrame):
                             "scene": a.scene, "width": W, "height": H, "spp": a.spp, "rays_per_frame": int(total_rays),
                             "parallelism": fr.parallelism(), "split": a.split if world > 1 else None,
                             "pipeline": bool(getattr(fr, "pipeline", False)), "ms_per_frame": round(ms_per_step, 3),
-                            "source_hash": source_hash(REPO)}, **d),
+                            "source_hash": source_hash(REPO),
+                            "ranks": {"kernel_ms_per_frame": [round(r[0], 3) for r in per_rank],
+                                      "kernel_ms_per_frame_min_max": [round(min(r[0] for r in per_rank), 3), round(max(r[0] for r in per_rank), 3)],
+                                      "counted_launch_tail_ms": [round(r[1], 3) for r in per_rank], "counted_launch_span_ms": [round(r[2], 3) for r in per_rank],
+                                      "collective_ms_per_frame": [round(r[3], 3) for r in per_rank], "rays_per_frame": [int(r[4]) for r in per_rank],
+                                      "comm_ranks_seen": (fr.ctx.get_option("comm_ranks") if getattr(fr, "use_comm", False) else 1) if hasattr(fr, "ctx") else world,
+                                      "note": "kernel ms: HIP events round the trace kernel on the launch stream; tail / span: s_memrealtime stamps of the counting "
+                                              "launch (work items ran out -> last wave out; first wave in -> last wave out); collective: wall time of "
+                                              "moptix_gather_tiles / moptix_reduce_frame incl. its stream synchronisation"}}, **d),
             "roofline": roof,
         }
         if fast is not None:

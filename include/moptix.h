@@ -98,7 +98,8 @@ typedef struct moptix_params {
 typedef struct moptix_stats {
   uint64_t samples;              /* camera samples traced                                 */
   uint64_t primaryRays, bounceRays, shadowRays;
-  uint64_t nodeFetches;          /* 128-byte four-child BVH nodes fetched (one L2 line)   */
+  uint64_t nodeFetches;          /* four-child BVH nodes fetched: 64-byte records where get_option "node_format_used" says 64
+                                    (variant 4 on scenes whose paths favour the quantised form), else 128-byte ones */
   uint64_t triTests;             /* 48-byte triangle records tested                       */
   uint64_t closestHits;          /* closest-hit shading fetches                           */
   uint64_t lightLoads;           /* LightParams records read for NEE                      */
@@ -204,7 +205,16 @@ int moptix_packed_tile_floats(moptix_context ctx, int32_t nRanks, uint64_t* outF
 int moptix_pack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, float* dstDevice);
 int moptix_unpack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, const float* srcDevice);
 
-/* tuning knobs (none of them changes a bit of the image):
+/* The one option that is NOT a tuning knob:
+ *   "shadow_rule"      1 (default): a shadow ray is decided by its NEAREST any-hit surface -- an opaque Disney surface gives (0,0,0), a
+ *                      Disney GLASS surface gives its colour and nothing behind it is looked at.  This is DEVIATION D5' from SURVEY A2
+ *                      ("an opaque surface anywhere on the segment blocks, every glass surface crossed multiplies"): it models what
+ *                      OptiX does with disneyAnyHit (Material.cu:225-232 accepts the glass hit, which ends the ray's interval) under a
+ *                      front-to-back traversal, and it is FITTED, not pinned: the evidence is the floor round the machine in
+ *                      demo/coffee.png with a stand-in for the missing pot; real Trbvh traversal is not strictly front
+ *                      to back.  0: SURVEY A2's order-independent rule (the oracle's switch shadow_any_opaque_blocks).  The two differ
+ *                      only in scenes with a Disney GLASS material (the benchmark scene has none); takes effect at the next render.
+ * tuning knobs (none of them changes a bit of the image):
  *   "kernel_variant"   0 per-lane kernel, 3 path slots and queues shared by the workgroup (variants 1 and 2 of rounds 1-2 are gone),
  *                      4 = 3 with one shading visit per bounce (pt_packet.h; scenes with <= 3 lights, else 3 runs).
  *                      While it has not been set: 4 for launches of >= 1e6 samples and >= 16 seeds on scenes that are not
@@ -215,8 +225,9 @@ int moptix_unpack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, const 
  *                      node step instead of 7, boxes up to a grid step larger), 0 (default) = whichever is cheaper for this scene
  *                      seen from this camera: decided at the first render after a build by walking one path per pixel of a
  *                      128-pixel-wide grid under both (get_option "node_format_used" tells the verdict)
- *   "slots_in_use"     path slots per 512-slot pool that carry a path (-1 = chosen per launch: 448 for variant 4 launches
- *                      under 1e8 samples, else all); the others are what deep paths borrow, see "aux_depth"
+ *   "slots_in_use"     path slots of a workgroup's pool (get_option "path_slots": 576 for variant 4, 512 for variant 3) that carry a
+ *                      path (-1 = chosen per launch: 7/8 of them for variant 4 launches under 1e8 samples, else all); the others
+ *                      are what deep paths borrow, see "aux_depth"
  *   "aux_depth"        variant 4: a path this deep (default 16; 0 = never) traces the shadow rays of each hit in slots
  *                      borrowed from finished paths, at the same time as the continuation ray (DESIGN.md "Borrowed slots")
  *   "analytic_queue"   scenes without triangles: 1 = through the queue kernel, 0 = per-lane kernel, -1 (default) = queue
@@ -234,6 +245,10 @@ int moptix_unpack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, const 
  *                      1: hardware reciprocal / square-root approximations there (the reference itself is built with
  *                      -use_fast_math, utils_host.cpp:30-32): same rays, BRDF weights within ~1e-6, default kernel only
  *   "watchdog_ms"      wall-clock bound of one render kernel (default 600000); a pass cut short is not accumulated
+ * read-only (get_option): "kernel_variant_used", "node_format_used", "path_slots", "num_cus", "comm_ranks" (size of the context's
+ *   communicator, 0 without one), and after moptix_render_counted
+ *   "counted_span_us" (first wave in -> last wave out of the trace kernel) / "counted_tail_us" (the part of it after the last
+ *   work item was handed out: the launch's drain; -1 for the per-lane kernel)
  * Unknown names -> MOPTIX_ERR_INVALID. */
 int moptix_set_option(moptix_context ctx, const char* name, int32_t value);
 int moptix_get_option(moptix_context ctx, const char* name, int32_t* value);

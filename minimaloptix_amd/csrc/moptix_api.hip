@@ -93,6 +93,8 @@ struct moptix_context_t {
   int optAnalyticQueue = -1;          // -1 = by primitive count
   int optAutoPacket = 1;
   int lastVariant = -1;              // what the last render ran (get_option "kernel_variant_used")
+  int countedSpanUs = -1, countedTailUs = -1;   // last counted launch: first wave in -> last wave out, and the part of it after the last work item was handed out
+  int optShadowRule = 1;             // 1 = a shadow ray is decided by its nearest any-hit surface (default), 0 = SURVEY A2's order-independent rule
   bool variantExplicit = false;      // kernel_variant was set by the caller: no automatic choice
   int optSlotsInUse = -1;            // -1 = chosen per launch from its size
   int optAuxDepth = 16;              // variant 4: depth from which a path's shadow rays get slots of their own (0 = off)
@@ -141,7 +143,8 @@ void fill_view(moptix_context c, SceneView& v) {
   for (size_t i = 0; i < c->spheres.size(); i++) if (c->mats[c->sphereMat[i]].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
   for (size_t i = 0; i < c->quads.size(); i++) if (c->mats[c->quads[i].mat].kind == MAT_DISNEY) v.anyDisneyAnalytic = 1;
   v.shadowNearest = 0;
-  for (const DevMaterial& m : c->mats) if (m.kind == MAT_DISNEY && m.brdfType == BRDF_GLASS) v.shadowNearest = 1;
+  if (c->optShadowRule != 0)          // option "shadow_rule": 0 keeps SURVEY A2's order-independent rule whatever the scene holds
+    for (const DevMaterial& m : c->mats) if (m.kind == MAT_DISNEY && m.brdfType == BRDF_GLASS) v.shadowNearest = 1;
   v.nTris = c->bvh.nTris; v.rootRef = c->bvh.nTris > 0 ? c->bvh.rootRef : kEmptyRef;
   v.nodes = c->bvh.nodes; v.nodes64 = c->nodeFormatUsed == 64 ? c->bvh.nodes64 : nullptr; v.tris = c->bvh.tris; v.triShade = c->bvh.shade;
   v.triUV = (c->anyUV && c->bvh.nTris > 0) ? c->dFaceUV.p : nullptr;
@@ -205,6 +208,9 @@ int read_stats(moptix_context c, moptix_stats* stats) {
   stats->nodeFetches = h[4]; stats->triTests = h[5]; stats->closestHits = h[6]; stats->lightLoads = h[7];
   stats->analyticTests = h[8]; stats->traversalSteps = h[9]; stats->activeLaneSteps = h[10];
   stats->shadeBatches = h[11]; stats->shadeBatchLanes = h[12];
+  // timeline of a counted launch (100 MHz s_memrealtime stamps of the queue kernels): options "counted_span_us" / "counted_tail_us"
+  c->countedSpanUs = -1; c->countedTailUs = -1;
+  if (h[38] && h[36] != ~0ull) { c->countedSpanUs = (int)((h[38] - h[36]) / 100); c->countedTailUs = (h[37] != ~0ull && h[38] > h[37]) ? (int)((h[38] - h[37]) / 100) : 0; }
   if (getenv("MOPTIX_DEBUG")) {
     fprintf(stderr, "[moptix] batches %llu lanes %llu full %llu allidle %llu waitingSum %llu\n", h[11], h[12], h[13], h[14], h[15]);
     const double tt = (double)h[21];
@@ -792,6 +798,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "builder")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "builder in {0,1}"); if (value != c->optBuilder) c->accelBuilt = false; c->optBuilder = value; }
   else if (!strcmp(name, "fast_shading")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "fast_shading in {0,1}"); c->optFastShading = value; }
   else if (!strcmp(name, "node_format")) { if (value != 0 && value != 64 && value != 128) return fail(c, MOPTIX_ERR_INVALID, "node_format in {0,64,128}"); if (value != c->optNodeFormat) c->formatDecided = false; c->optNodeFormat = value; }
+  else if (!strcmp(name, "shadow_rule")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "shadow_rule in {0,1}"); c->optShadowRule = value; }
   else if (!strcmp(name, "watchdog_ms")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "watchdog_ms >= 1"); c->optWatchdogMs = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
@@ -818,6 +825,11 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "analytic_queue")) *value = c->optAnalyticQueue;
   else if (!strcmp(name, "auto_packet")) *value = c->optAutoPacket;
   else if (!strcmp(name, "kernel_variant_used")) *value = c->lastVariant;
+  else if (!strcmp(name, "shadow_rule")) *value = c->optShadowRule;
+  else if (!strcmp(name, "counted_span_us")) *value = c->countedSpanUs;
+  else if (!strcmp(name, "counted_tail_us")) *value = c->countedTailUs;
+  else if (!strcmp(name, "path_slots")) *value = packetkernel_slots();
+  else if (!strcmp(name, "comm_ranks")) *value = c->comm ? c->commRanks : 0;
   else if (!strcmp(name, "num_cus")) *value = c->numCUs;
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;

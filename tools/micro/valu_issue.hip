@@ -82,8 +82,7 @@
   X(66, "cmp(vcc)+2cndmask_indep[3]", "v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 v40, %0, %2, vcc\n v_cndmask_b32 v41, %2, %0, vcc") \
   X(67, "cmp_e64(s)+2cndmask_e64_indep[3]", "v_cmp_lt_f32_e64 s[20:21], %0, %1\n v_cndmask_b32_e64 v40, %0, %2, s[20:21]\n v_cndmask_b32_e64 v41, %2, %0, s[20:21]") \
   X(68, "v_cndmask_b32(vcc,literal0)", "v_cndmask_b32 %0, 0, %0, vcc") \
-  X(69, "v_addc_co_u32(vcc)", "v_addc_co_u32 %0, vcc, %0, %1, vcc") \
-  X(70, "v_cmp_lt_f32+s_and_saveexec-free:v_cmpx-ish:v_cmp_e64_then_s_and", "v_cmp_lt_f32_e64 s[20:21], %0, %1\n s_and_b64 s[20:21], s[20:21], exec")
+  X(69, "v_addc_co_u32(vcc)", "v_addc_co_u32 %0, vcc, %0, %1, vcc")
 // 64-bit accumulators (register pairs)
 #define KINDS64(X) \
   X(100, "v_pk_fma_f32", "v_pk_fma_f32 %0, %0, %1, %2") \
