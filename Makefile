@@ -4,6 +4,7 @@
 #   make host       -> minimaloptix_amd/lib/libmoptix_host.so, minimaloptix_amd/lib/moptix_render
 #   make oracle     -> oracle/liboracle.so                      (test infrastructure)
 #   make hostsim    -> tests/hostsim/libhostsim.so              (test infrastructure)
+#   make loopback   -> tests/rccl_loopback/librccl_loopback.so  (test infrastructure: N ranks on one GPU without RCCL)
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
 ARCH     ?= gfx950
@@ -29,7 +30,7 @@ HOST_SRCS := $(HOST)/obj_loader.cpp $(HOST)/scene_file.cpp $(HOST)/scenes.cpp $(
 HOST_OBJS := $(patsubst $(HOST)/%.cpp,build/host_%.o,$(HOST_SRCS))
 HOST_HDRS := $(wildcard $(HOST)/*.h) $(wildcard $(CSRC)/pt_*.h) include/moptix.h include/moptix_host.h
 
-all: device host oracle hostsim
+all: device host oracle hostsim loopback
 
 device: $(LIBDIR)/$(LIBNAME)
 host: $(LIBDIR)/libmoptix_host.so $(LIBDIR)/moptix_render
@@ -37,6 +38,8 @@ oracle:
 	$(MAKE) -C oracle -s
 hostsim:
 	$(MAKE) -C tests/hostsim -s
+loopback:
+	$(MAKE) -C tests/rccl_loopback -s
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(DEV_HDRS) Makefile
 	@mkdir -p $(BUILD)
@@ -57,6 +60,6 @@ $(LIBDIR)/moptix_render: $(HOST)/main.cpp $(LIBDIR)/libmoptix_host.so
 	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/main.cpp -L$(LIBDIR) -lmoptix_host -lmoptix -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 clean:
-	rm -rf build $(LIBDIR)/*.so $(LIBDIR)/moptix_render oracle/liboracle.so tests/hostsim/libhostsim.so
+	rm -rf build $(LIBDIR)/*.so $(LIBDIR)/moptix_render oracle/liboracle.so tests/hostsim/libhostsim.so tests/rccl_loopback/librccl_loopback.so
 
-.PHONY: all device host oracle hostsim clean
+.PHONY: all device host oracle hostsim loopback clean

@@ -7,7 +7,9 @@
 #include <string>
 #include <vector>
 
+#include <signal.h>
 #include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "minimal_optix.h"
@@ -19,6 +21,8 @@ static void usage() {
           "                     [--autosave] [--device D] [--random-seeds] [--strict-missing]\n"
           "       multi-GPU (one process per GPU, tile split + RCCL gather to rank 0, which writes the image):\n"
           "                     [--spawn N]  start N ranks of this program, rank r on device r, and wait for them\n"
+          "                     [--spawn-same-device]  ... every rank on --device (a one-GPU box; needs a transport that accepts it,\n"
+          "                                            MOPTIX_RCCL_LIB)   [--spawn-timeout S]  deadline of the ranks (default 600)\n"
           "                     [--rank R --ranks N --comm-file PATH]  one rank of a job started by something else\n");
 }
 
@@ -26,7 +30,7 @@ int main(int argc, char** argv) {
   std::string scene = "spheres", prefix = "frame", scenes = "scenes/", outdir = ".";
   unsigned spp = 32, width = 1920, height = 1080, seed = 0;
   int device = 0; bool autosave = false, randomSeeds = false, strict = false;
-  int rank = 0, ranks = 1, spawn = 0; std::string commFile;
+  int rank = 0, ranks = 1, spawn = 0, spawnTimeout = 600; bool spawnSame = false; std::string commFile;
   for (int i = 1; i < argc; i++) {
     auto need = [&](const char* n) { if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", n); exit(2); } return argv[++i]; };
     if (!strcmp(argv[i], "--scene")) scene = need("--scene");
@@ -42,6 +46,8 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--ranks")) ranks = atoi(need("--ranks"));
     else if (!strcmp(argv[i], "--comm-file")) commFile = need("--comm-file");
     else if (!strcmp(argv[i], "--spawn")) spawn = atoi(need("--spawn"));
+    else if (!strcmp(argv[i], "--spawn-same-device")) spawnSame = true;
+    else if (!strcmp(argv[i], "--spawn-timeout")) spawnTimeout = atoi(need("--spawn-timeout"));
     else if (!strcmp(argv[i], "--autosave")) autosave = true;
     else if (!strcmp(argv[i], "--random-seeds")) randomSeeds = true;
     else if (!strcmp(argv[i], "--strict-missing")) strict = true;
@@ -57,12 +63,34 @@ int main(int argc, char** argv) {
     for (int r = 0; r < spawn && !child; r++) {
       pid_t pid = fork();
       if (pid < 0) { perror("fork"); return 1; }
-      if (pid == 0) { child = true; rank = r; ranks = spawn; device = r; commFile = idFile; }
+      if (pid == 0) { child = true; rank = r; ranks = spawn; if (!spawnSame) device = r; commFile = idFile; }
       else kids.push_back(pid);
     }
     if (!child) {
-      int worst = 0;
-      for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128; if (rc > worst) worst = rc; }
+      // The ranks meet in collectives: one that dies (or never arrives) leaves its peers waiting for ever.  So the parent polls: the
+      // first rank that fails, or the deadline, ends the others (SIGKILL), and the exit code says which it was (124 = deadline).
+      int worst = 0; size_t live = kids.size();
+      std::vector<bool> done(kids.size(), false);
+      const time_t t0 = time(nullptr);
+      while (live > 0) {
+        for (size_t i = 0; i < kids.size(); i++) {
+          if (done[i]) continue;
+          int st = 0;
+          if (waitpid(kids[i], &st, WNOHANG) == kids[i]) {
+            done[i] = true; live--;
+            const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
+            if (rc > worst) worst = rc;
+          }
+        }
+        const bool late = time(nullptr) - t0 > spawnTimeout;
+        if (live > 0 && (worst != 0 || late)) {
+          fprintf(stderr, "moptix_render --spawn: %s; ending the other %zu rank(s)\n", late ? "deadline passed" : "a rank failed", live);
+          for (size_t i = 0; i < kids.size(); i++) if (!done[i]) { kill(kids[i], SIGKILL); waitpid(kids[i], nullptr, 0); }
+          if (late && worst == 0) worst = 124;
+          break;
+        }
+        if (live > 0) usleep(20000);
+      }
       remove(idFile.c_str());
       return worst;
     }

@@ -381,6 +381,42 @@ def test_shadow_rays_through_glass_nearest_any_hit_surface_decides(gpu_ctx, tmp_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 3, 4])
+def test_shadow_rule_0_is_survey_a2_order_independent_rule(gpu_ctx, tmp_path, variant):
+    """moptix_set_option("shadow_rule", 0): the contract SURVEY A2 wrote down -- an opaque Disney surface anywhere on the segment
+    blocks, every glass surface crossed multiplies -- stays available on the device (the default, 1, is the nearest-any-hit rule
+    fitted to demo/coffee.png: deviation D5' in include/moptix.h).  Every kernel against the oracle's switch
+    shadow_any_opaque_blocks, on the glass-over-opaque scene where the two rules give different images."""
+    from common import write_glass_over_opaque_scene
+    from oracle import oracle as O
+    hs = M.HostScene("file:cornell", 96, 72, base_folder=write_glass_over_opaque_scene(tmp_path, True))
+    seeds = M.launch_seeds(6)
+    default = gpu_ctx.get_option("kernel_variant")
+    imgs = {}
+    try:
+        gpu_ctx.set_option("kernel_variant", variant)
+        for rule in (1, 0):
+            gpu_ctx.set_option("shadow_rule", rule)
+            assert gpu_ctx.get_option("shadow_rule") == rule
+            gpu_ctx.load(hs); gpu_ctx.accum_clear()
+            st = gpu_ctx.render_counted(seeds)
+            imgs[rule] = (gpu_ctx.accum_read(), st)
+    finally:
+        gpu_ctx.set_option("shadow_rule", 1); gpu_ctx.set_option("kernel_variant", default)
+    try:
+        O.set_option("shadow_any_opaque_blocks", 1)
+        o0, ost0 = oracle_scene(hs).render(seeds)
+    finally:
+        O.set_option("shadow_any_opaque_blocks", 0)
+    o1, ost1 = oracle_scene(hs).render(seeds)
+    g1, st1 = imgs[1]
+    g0, st0 = imgs[0]
+    assert rmse(g1 / 6, o1 / 6) <= RMSE_TIGHT and st1.rays == ost1.rays
+    assert rmse(g0 / 6, o0 / 6) <= RMSE_TIGHT and st0.rays == ost0.rays and st0.shadowRays == ost0.shadowRays
+    assert rmse(g0 / 6, g1 / 6) > 1e-3                 # the rules differ here: the opaque pane behind the glass blocks under A2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scene,kw", [("file:coffee", {}), ("coffee_pot_standin", {}), ("dining_standin", dict(iarg=2))])
 def test_node_format_changes_the_work_never_the_image(gpu_ctx, scene, kw):
     """Option node_format (variant 4): the 64-byte nodes hold every child box rounded outwards on a 256-step grid, so the

@@ -1,0 +1,68 @@
+"""The N > 1 branches of moptix_gather_tiles / moptix_reduce_frame as N processes on ONE GPU.
+
+RCCL refuses a communicator whose ranks share a device ("Duplicate GPU detected": tried in round 4, tools/rccl_two_ranks.py
+--same-device without a transport override), and no multi-GPU box has been available.  So the nine ncclXxx entry points that
+libmoptix.so binds are stood in for by tests/rccl_loopback (shared memory + hipMemcpy, MOPTIX_RCCL_LIB): what runs here is
+everything on this project's side of those calls -- pack kernel -> send, grouped receives -> per-rank unpack kernels, the
+reduce call, the partition / communicator checks, `moptix_render --spawn N` with its id file -- NOT RCCL and not xGMI."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import M, REPO
+
+LOOPBACK = os.path.join(REPO, "tests", "rccl_loopback", "librccl_loopback.so")
+
+
+def _env():
+    e = dict(os.environ)
+    e["MOPTIX_RCCL_LIB"] = LOOPBACK
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3])
+def test_n_ranks_gather_and_reduce_through_the_c_abi(n):
+    """N processes, one context each on device 0: tile split + moptix_gather_tiles is bit-identical to the one-rank frame,
+    sample split + moptix_reduce_frame equals it within the summation-order bound (dist.SAMPLE_SPLIT_TOL)."""
+    assert os.path.exists(LOOPBACK), "make -C tests/rccl_loopback"
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "rccl_two_ranks.py"), str(n), "--same-device"],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    assert "bit-identical to the one-rank frame" in p.stdout and ("over %d ranks" % n) in p.stdout, p.stdout[-1000:]
+
+
+def _read_png(path):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_gpu_configs import _read_png as rp
+    return rp(path)
+
+
+@pytest.mark.gpu
+def test_cli_spawn_2_ranks_on_one_gpu(tmp_path):
+    """moptix_render --spawn 2 --spawn-same-device: the parent forks two ranks before anything touches the GPU, rank 0 publishes the
+    communicator id through the file, both render their tiles, moptix_gather_tiles brings rank 1's tiles to rank 0, which writes
+    the frame: the same bytes as the plain run."""
+    exe = os.path.join(REPO, "minimaloptix_amd", "lib", "moptix_render")
+    common = ["--scene", "spheres", "--spp", "3", "--width", "160", "--height", "90", "--outdir", str(tmp_path), "--scenes", M.scenes_dir()]
+    r1 = subprocess.run([exe] + common + ["--out", "one"], capture_output=True, text=True, timeout=300)
+    r2 = subprocess.run([exe] + common + ["--out", "two", "--spawn", "2", "--spawn-same-device", "--spawn-timeout", "120"],
+                        env=_env(), capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-1500:], r2.stderr[-1500:])
+    assert np.array_equal(_read_png(os.path.join(str(tmp_path), "one.png")), _read_png(os.path.join(str(tmp_path), "two.png")))
+
+
+@pytest.mark.gpu
+def test_cli_spawn_ends_the_other_ranks_when_one_fails(tmp_path):
+    """A rank that dies must not leave its peers (and the parent's wait) blocked for ever: with real RCCL on this one-GPU box
+    ncclCommInitRank fails in every rank ("Duplicate GPU"), the parent reports the failure and exits non-zero, within its deadline."""
+    exe = os.path.join(REPO, "minimaloptix_amd", "lib", "moptix_render")
+    args = ["--scene", "spheres", "--spp", "1", "--width", "64", "--height", "36", "--outdir", str(tmp_path), "--scenes", M.scenes_dir(),
+            "--out", "x", "--spawn", "2", "--spawn-same-device", "--spawn-timeout", "90"]
+    e = dict(os.environ); e.pop("MOPTIX_RCCL_LIB", None)
+    r = subprocess.run([exe] + args, env=e, capture_output=True, text=True, timeout=200)
+    assert r.returncode != 0, r.stderr[-1000:]

@@ -172,6 +172,49 @@ def test_floor_round_the_machine_is_lit_through_the_glass_pot():
         assert abs(g_old_rule[n] - g_shipped[n]) < 0.003, (n, g_old_rule)
 
 
+def _coffee_comparable_blocks(gold):
+    """Everything but the glass pot itself (its shape is unknown: Mesh010.obj is missing upstream) and a two-block margin round
+    strong edges of the PNG, whose frame is displaced by 3-5 pixels against the checkout's camera."""
+    lum = gold.mean(axis=2)
+    edge = np.zeros_like(lum, bool)
+    edge[:, 1:] |= np.abs(np.diff(lum, axis=1)) > 0.06
+    edge[1:, :] |= np.abs(np.diff(lum, axis=0)) > 0.06
+    grown = edge.copy()
+    for dy in range(-2, 3):
+        for dx in range(-2, 3):
+            grown |= np.roll(np.roll(edge, dy, axis=0), dx, axis=1)
+    comparable = ~grown
+    comparable[74:120, 94:160] = False
+    return comparable
+
+
+def test_coffee_census_over_all_comparable_blocks_is_frozen():
+    """The parity chapter as a regression test: of the 32,400 8x8-pixel blocks of demo/coffee.png 23,386 are
+    comparable; per block, max over R, G, B of |oracle - PNG|.  profiles/r03_oracle_coffee_analysis.txt has the table at 1,024 spp
+    (shipped scene 91.3 % within 0.02; pot stand-in + nearest-any-hit shadow rule + two-ulp cosine 98.0 %); here at 384 spp, where
+    ~0.007 of sampling noise per block lowers both (88.2 % / 93.0 % within 0.02, 94.0 % / 98.2 % within 0.03).  An oracle edit
+    that moves the image against the reference's PNG fails here."""
+    gold = np.load(os.path.join(GOLD, "coffee_8x.npy")).astype(np.float64)
+    comparable = _coffee_comparable_blocks(gold)
+    assert int(comparable.sum()) == 23386
+    spp = 384
+    seeds = M.launch_seeds(spp)
+
+    def census(kind):
+        acc, _ = oracle_scene(M.HostScene(kind, 240, 135)).render(seeds)
+        dd = np.abs(O.image_from_accum(acc, spp).astype(np.float64) - gold).max(axis=2)[comparable]
+        return float((dd <= 0.02).mean()), float((dd <= 0.03).mean())
+    shipped = census("file:coffee")
+    try:
+        O.set_option("cos_short_tenth_ulp", 20)
+        fitted = census("coffee_pot_standin")
+    finally:
+        O.set_option("cos_short_tenth_ulp", 0)
+    assert shipped[0] >= 0.875 and shipped[1] >= 0.935, shipped
+    assert fitted[0] >= 0.925 and fitted[1] >= 0.977, fitted
+    assert fitted[0] - shipped[0] >= 0.035, (shipped, fitted)          # what the pot + the shadow rule + the cosine explain
+
+
 def test_stack_overflow_exception_does_not_explain_the_coffee_gap():
     """Hypothesis tested in round 3: the reference's 9608-byte OptiX stack (MinimalOptiX.cpp:134) overflows at some recursion
     depth D and Exception.cu adds white instead of the sample.  render_by_depth gives the image for every D from one render:
