@@ -145,13 +145,14 @@ typedef __attribute__((address_space(3))) int lds_int;
 // overflow path into one flat_load).
 // stack[slot][0]: bits 0-7 stack pointer, the rest describes the packet in flight
 constexpr int kSpMask = 0xff;
-// The continuation's nearest hit is a TRIANGLE (set by the leaf pass that writes such a hit; the brute-force lists at a ray's
-// start leave it clear): the finished packet goes to Q_SHADE, whose batches run the mesh materials -- on the benchmark scene the
-// Disney program, ~3,000 vector instructions.  Every other finished packet (continuation missed, hit a light quad or another
-// analytic primitive, or there was no continuation) goes to Q_GEN: its visit folds the shadow results, runs miss / the
-// analytic primitive's program and, where the sample ended, takes the next work item in the same visit.  Until round 4 every
-// packet with shadow rays went to Q_SHADE: its batches then ran the Disney code with 34 of 64 lanes (profiles/r04_lane_census.txt),
-// and a sample that ended on a miss needed a second visit for its new work item.
+// The continuation's nearest hit is a triangle with a Disney material that is not glass (Tri48::shadow == SHADOW_OPAQUE; kept up to
+// date by the leaf pass that writes a nearer hit; the brute-force lists at a ray's start leave it clear): the finished packet goes
+// to Q_SHADE, whose batches run the Disney program -- ~3,000 vector instructions.  Every other finished packet (continuation missed,
+// hit a light quad or another analytic primitive, hit glass / a non-Disney mesh material, or there was no continuation) goes to
+// Q_GEN: its visit folds the shadow results, runs miss / the cheap material program and, where the sample ended, takes the next
+// work item in the same visit.  Until round 4 every packet with shadow rays went to Q_SHADE: its batches then ran the Disney code
+// with 34 of 64 lanes on the benchmark scene (12 of 64 on the glass knot: profiles/r04_lane_census.txt), and a sample that ended
+// on a miss needed a second visit for its new work item.
 constexpr int kShadeFlag = 1 << 30;
 constexpr int kShadowRay = 1 << 29;   // the ray in flight is a shadow ray (MinimalOptiX.h:48 RAY_TYPE_SHADOW)
 constexpr int kHitValid = 1 << 28;    // SlotCold::hit holds the continuation's nearest hit so far
@@ -488,7 +489,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         ps.tmax = shadow ? na.w : kRtDefaultMax;
         tv.inv = mk3(0.f, 0.f, 0.f); tv.tbest = na.w;      // the leaf step does not use 1/d
         tv.node = node0; tv.sp = fl & kSpMask;
-        tv.bestTri = -1; tv.bestPrim = -1; tv.beta = 0.f; tv.gamma = 0.f; tv.att = mk3(1.f, 1.f, 1.f);
+        tv.bestTri = -1; tv.bestPrim = -1; tv.beta = 0.f; tv.gamma = 0.f; tv.att = mk3(1.f, 1.f, 1.f); tv.bestCls = SHADOW_NONE;
         if (shadow) { if (fl_stat(fl, cur) == 2) { tv.att = mk3(wr.x, wr.y, wr.z); if (sc.shadowNearest) tv.bestPrim = f2i(wr.w); } }
         else if (hitValid) tv.bestPrim = kPrimUnknown;       // "some primitive at tbest": any candidate at exactly tbest passes potential() for now
         const int oldPrim = tv.bestPrim;
@@ -516,7 +517,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           if (hitValid && tv.tbest == na.w) { const v4 held = slot_load(&cs->hit); PT_ROWS(2, 1); keep = !(f2i(held.y) < tv.bestPrim); }
           if (keep) {
             slot_store(&cold[slot].hit, mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma)); PT_ROWS(3, 1);
-            nfl |= kHitValid | kShadeFlag;
+            nfl = (nfl & ~kShadeFlag) | kHitValid | (tv.bestCls == SHADOW_OPAQUE ? kShadeFlag : 0);
           }
         }
         if (tv.node == kTravDone && more) {

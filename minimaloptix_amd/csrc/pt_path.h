@@ -50,6 +50,7 @@ struct Trav {
   float tbest;     // radiance: nearest accepted t so far; shadow: the ray's tmax
   int bestPrim;    // primitive id of the nearest hit (spheres, quads, triangles) or -1
   int bestTri;     // record index of the nearest triangle, or -1
+  int bestCls;     // Tri48::shadow of that triangle (SHADOW_OPAQUE = a Disney surface that is not glass): what program its hit will run
   float beta, gamma;
   v3 att;          // shadow attenuation (disneyAnyHit)
   v3 inv;          // 1/d
@@ -395,7 +396,7 @@ PT_HD void trav_leaf_step_fetched(const SceneView& sc, const PathState& ps, Trav
             census<CNT>(ct, CR_TRI_HIT);
             if (ps.kind == RK_RADIANCE) {
               if (potential(t, triBase + ch.prim[j], ps.tmin, tv.tbest, tv.bestPrim)) {
-                tv.tbest = t; tv.bestPrim = triBase + ch.prim[j]; tv.bestTri = first + base + j; tv.beta = be; tv.gamma = ga;
+                tv.tbest = t; tv.bestPrim = triBase + ch.prim[j]; tv.bestTri = first + base + j; tv.beta = be; tv.gamma = ga; tv.bestCls = ch.shadow[j];
               }
             } else if (sc.shadowNearest) {
               shadow_candidate_tri(sc, ch.shadow[j], ch.mat[j], t, triBase + ch.prim[j], ps.tmin, tv.tbest, tv.bestPrim, tv.att);

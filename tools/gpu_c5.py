@@ -1,19 +1,24 @@
-"""C4 / C5 stand-ins at 1920x1080x16: kernel variant and slot options (OPTS sets, one per line of CASES)."""
-import os, sys
+"""BASELINE configs 4 and 5 (dining-room and glass-knot stand-ins) under option sets: trace-kernel time + image hash.
+   OPTSETS="kernel_variant=3;kernel_variant=4,node_format=64;kernel_variant=4,node_format=128" python tools/gpu_c5.py"""
+import hashlib, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
-from common import M   # noqa: E402
-ctx = M.Context(0)
-scenes = {"c4": ("dining_standin", dict(iarg=6)), "c5": ("million_standin", dict(iarg=1000000))}
-seeds = M.launch_seeds(int(os.environ.get("SPP", "16")))
-for name in os.environ.get("SCENES", "c5,c4").split(","):
-    kind, kw = scenes[name]
-    hs = M.HostScene(kind, 1920, 1080, **kw)
-    for case in os.environ.get("CASES", "kernel_variant=3;kernel_variant=4,aux_depth=0,slots_in_use=512;kernel_variant=4,aux_depth=16,slots_in_use=512;kernel_variant=4,aux_depth=16,slots_in_use=448").split(";"):
-        for o in case.split(","):
-            k, v = o.split("="); ctx.set_option(k, int(v))
+import minimaloptix_amd as M
+scenes = [("million_standin", dict(iarg=1000000), (1920, 1080), 16), ("dining_standin", dict(iarg=6), (1920, 1080), 16)]
+for kind, kw, res, spp in scenes:
+    hs = M.HostScene(kind, res[0], res[1], **kw); seeds = M.launch_seeds(spp)
+    for optset in os.environ.get("OPTSETS", "kernel_variant=3;kernel_variant=4,node_format=64;kernel_variant=4,node_format=128").split(";"):
+        ctx = M.Context(0); ctx.set_option("watchdog_ms", 60000)
+        for o in optset.split(","):
+            if "=" in o:
+                k, v = o.split("="); ctx.set_option(k, int(v))
         ctx.load(hs)
+        ctx.accum_clear(); st = ctx.render_counted(seeds)
         best = 1e9
         for rep in range(3):
             ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); ms, n = ctx.kernel_time(); best = min(best, ms)
-        print("%s %-60s %.1f ms (variant used %d)" % (name, case, best, ctx.get_option("kernel_variant_used")), flush=True)
+        img = ctx.accum_read()
+        print("%-16s %-40s %7.2f ms %7.1f Mrays/s  per ray %.2f nodes %.2f tris  variant %d nodes %d B  hash %s" % (
+            kind, optset, best, st.rays / best / 1e3, st.nodeFetches / st.rays, st.triTests / st.rays, ctx.get_option("kernel_variant_used"),
+            ctx.get_option("node_format_used") if ctx.get_option("kernel_variant_used") == 4 else 128, hashlib.md5(img.tobytes()).hexdigest()[:10]), flush=True)
+        ctx.close()

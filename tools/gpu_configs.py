@@ -25,8 +25,13 @@ def timing(kind, kw, res, spp):
         # (plane t 11 incl. the division as one, point 6 -> two projected-edge dots are not reached by most rays, 3 counted)
         nS, nQ = hs.sizes.nSpheres, hs.sizes.nQuads
         flops = st.analyticTests * (17.0 * nS + 20.0 * nQ) / max(1, nS + nQ)
-        print("       %-16s FP32: %.3g primitive tests x %.1f flop = %.2f TFLOP/s = %.3f of the 157.3 TFLOP/s vector peak" % (
-            kind, st.analyticTests, (17.0 * nS + 20.0 * nQ) / max(1, nS + nQ), flops / ms / 1e9, flops / ms / 1e9 / 157.3), flush=True)
+        import bench
+        v = bench.valu_ceilings(REPO)
+        p3, p8 = v["v_fma_f32"][3] * 0.128, v["v_fma_f32"][8] * 0.128      # measured: G v_fma_f32/s x 64 lanes x 2 flop (profiles/r04_valu_ceiling.txt)
+        tf = flops / ms / 1e9
+        print("       %-16s FP32: %.3g primitive tests x %.1f flop = %.2f TFLOP/s = %.3f of the measured v_fma_f32 rate at the kernel's 3 waves per SIMD "
+              "(%.1f TFLOP/s), %.3f of the best measured (8 waves per SIMD, %.1f), %.3f of the 157.3 TFLOP/s spec" % (
+            kind, st.analyticTests, (17.0 * nS + 20.0 * nQ) / max(1, nS + nQ), tf, tf / p3, p3, tf / p8, p8, tf / 157.3), flush=True)
     return ctx.resolve_rgb8(spp)
 parity("cornell_quads", {}, (256, 256), 4)
 parity("random_spheres", dict(iarg=497), (160, 90), 2)
