@@ -2,7 +2,29 @@
 // Host-side staging of the scene, upload, LBVH build, launches, read-back, measurement.
 // There is no CPU path: every entry point that computes needs a HIP device.
 #include <hip/hip_runtime.h>
+// RCCL's types and prototypes: from its header where there is one, else the handful this file needs (the library is bound at
+// run time by name, see load_rccl; a build box without the RCCL package -- or `make EXTRA=-DMOPTIX_NO_RCCL_HEADER` -- still
+// builds the whole library, and moptix_comm_* answer MOPTIX_ERR_STATE where no librccl can be loaded).
+#if !defined(MOPTIX_NO_RCCL_HEADER) && __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+const char* ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, int root, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+}
+#endif
 #include <rocprim/rocprim.hpp>
 
 #include <dlfcn.h>
@@ -564,6 +586,9 @@ int moptix_set_params(moptix_context c, const moptix_params* p) {
   if (!c || !p) return fail(c, MOPTIX_ERR_INVALID, "null argument");
   if (p->width == 0 || p->height == 0) return fail(c, MOPTIX_ERR_INVALID, "zero-sized launch");
   const bool resized = !c->haveParams || p->width != c->params.width || p->height != c->params.height;
+  // the node format is chosen by walking the scene's own paths from THIS camera (choose_node_format): a new camera or frame
+  // size asks again at the next render (two probe launches, ~2 ms; scenes without a tree or with "node_format" set skip it)
+  if (!c->haveParams || resized || memcmp(&p->cam, &c->params.cam, sizeof(p->cam)) != 0) c->formatDecided = false;
   c->params = *p; c->haveParams = true;
   if (resized && !c->accumBound) { c->accumPixels = 0; }
   return MOPTIX_OK;
