@@ -84,6 +84,12 @@ int queuekernel_slots();
 size_t queuekernel_cold_bytes(int nBlocks);
 size_t queuekernel_overflow_ints(int nBlocks, int ovfDepth);
 hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading);
+// queuekernel_lean.hip: the same kernel with four workgroups per CU, for scenes without triangles
+int queuekernel_lds_stack_entries_lean();
+int queuekernel_slots_lean();
+size_t queuekernel_cold_bytes_lean(int nBlocks);
+size_t queuekernel_overflow_ints_lean(int nBlocks, int ovfDepth);
+hipError_t launch_queuekernel_lean(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading);
 int packetkernel_lds_stack_entries();
 int packetkernel_slots();             // path slots per workgroup (variant 4)
 size_t packetkernel_cold_bytes(int nBlocks);

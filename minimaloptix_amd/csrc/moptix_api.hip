@@ -301,9 +301,9 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   if (a.nItems == 0) return MOPTIX_OK;
   const long long budget = (long long)c->optSampleBufMB << 20;
   long long perPass = budget / ((long long)a.nItems * 12);
-  const int nBlocks = c->numCUs * c->optBlocksPerCU;
+  int nBlocks = c->numCUs * c->optBlocksPerCU;
   // the work counter is a 32-bit int that every path slot bumps once more after the items ran out
-  const long long counterSlack = (long long)nBlocks * 1024 + 65536;
+  const long long counterSlack = (long long)c->numCUs * std::max(4, c->optBlocksPerCU) * 1024 + 65536;      // the lean queue kernel runs four workgroups per CU
   if ((long long)a.nItems + counterSlack > 0x7fffffffLL) return fail(c, MOPTIX_ERR_LIMIT, "frame too large");
   perPass = std::min(perPass, (0x7fffffffLL - counterSlack) / a.nItems);
   perPass = std::max(1LL, std::min(perPass, (long long)nSeeds));
@@ -327,6 +327,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   const bool autoPacket = nSamples >= 1.0e6 && nSeeds >= 16 && c->glassFaceShare <= 0.5;
   const bool usePacket = packetOk && (c->optVariant == 4 || (!c->variantExplicit && c->optAutoPacket != 0 && autoPacket));
   const bool useQueue = !usePacket && (c->optVariant >= 3) && (hasTris || analyticQueue);
+  const bool leanQueue = useQueue && !hasTris;      // scenes without triangles: queuekernel_lean.hip
   c->lastVariant = usePacket ? 4 : useQueue ? 3 : 0;
   a.starveLanes = c->optStarveLanes; a.swapLanes = c->optSwapLanes;
   // Slots without a path are what deep paths borrow for their shadow rays (packetkernel.hip, "aux_depth"); once the work
@@ -343,6 +344,12 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
       a.stackOverflow = c->dOverflow.p;
     }
     HIPCHK(c, c->dPoolCold.ensure(packetkernel_cold_bytes(nBlocks)), "alloc path pool");
+    a.poolCold = c->dPoolCold.p;
+  } else if (useQueue && leanQueue) {
+    // no tree to walk (queuekernel_lean.hip): a fourth workgroup per CU instead of path slots and stack entries
+    if (c->optBlocksPerCU == 3) nBlocks = c->numCUs * 4;
+    a.ovfDepth = 0;
+    HIPCHK(c, c->dPoolCold.ensure(queuekernel_cold_bytes_lean(nBlocks)), "alloc path pool");
     a.poolCold = c->dPoolCold.p;
   } else if (useQueue) {
     a.ovfDepth = std::max(0, c->bvh.stackBound - queuekernel_lds_stack_entries() + 1);
@@ -415,6 +422,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
     if (usePacket) HIPCHK(c, launch_packetkernel(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch packet megakernel");
+    else if (useQueue && leanQueue) HIPCHK(c, launch_queuekernel_lean(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch queue megakernel (lean)");
     else if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch queue megakernel");
     else HIPCHK(c, launch_megakernel(c->stream, a, nBlocks, counted), "launch megakernel");
     HIPCHK(c, hipEventRecord(c->ev1, c->stream), "event");

@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         if (pk.hasBounce) {
           Trav tv;
           ps.kind = RK_RADIANCE;
-          trav_begin<CNT>(sc, ps, tv, ct);
+          trav_begin<CNT, false>(sc, ps, tv, ct);
           tb0 = tv.tbest; bp0 = tv.bestPrim;
         }
         const bool hitNow = bp0 >= 0;

@@ -122,7 +122,11 @@ PT_HD float slab_inv(float d) { return 1.0f / (__builtin_fabsf(d) < 1e-30f ? __b
 PT_HD v3 neg_o_inv(v3 o, v3 inv) { return mk3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); }
 
 // Brute-force lists ("NoAccel" groups and the light geometry) + set-up of the BVH walk.
-template <bool CNT>
+// WINDOW: the chunked sphere loop looks at a sphere's roots with the hardware square root first (below).  The packet kernel (variant
+// 4) passes false: its scenes are triangle meshes with a handful of analytic primitives at most, the chunk never runs there, and
+// with the window test compiled in its register allocation came out with 69 spilled vector registers instead of 5 (+7 % on the
+// benchmark frame); without the chunk altogether with 37.  The allocation of that kernel is that fragile (NOTEBOOK.md).
+template <bool CNT, bool WINDOW = true>
 PT_HD void trav_begin(const SceneView& sc, const PathState& ps, Trav& tv, Counters& ct) {
   tv.tbest = ps.tmax; tv.bestPrim = -1; tv.bestTri = -1; tv.beta = 0.f; tv.gamma = 0.f;
   tv.att = mk3(1.f, 1.f, 1.f);
@@ -151,7 +155,17 @@ PT_HD void trav_begin(const SceneView& sc, const PathState& ps, Trav& tv, Counte
       }
 #pragma unroll
       for (int k = 0; k < PT_SPHERE_CHUNK; k++) {
-        if (!(dq[k] < 0)) {
+        // The correctly rounded roots (~35 instructions) only for spheres whose roots can fall into the window (tmin, tbest]: a first
+        // look with the hardware square root (1 ulp) and a margin of 1e-4 of the magnitudes involved, a thousand times its error, so a
+        // sphere the exact code would accept always passes (the exact code then decides, with the same operations as before).  A
+        // wave runs the exact code when ANY of its 64 rays' lines meets the sphere -- most spheres, before this test.
+        bool look = !(dq[k] < 0);
+        if constexpr (WINDOW) {
+          const float sa = __builtin_amdgcn_sqrtf(fmaxf_(dq[k], 0.f));
+          const float margin = 1e-4f * (1.f + __builtin_fabsf(bq[k]) + sa);
+          look = look && (sa - bq[k]) > ps.tmin - margin && (-bq[k] - sa) < tv.tbest + margin;
+        }
+        if (look) {
           const float sq = __builtin_sqrtf(dq[k]);
           const float t1 = -bq[k] - sq, t2 = -bq[k] + sq;
           if (potential(t1, i0 + k, ps.tmin, tv.tbest, tv.bestPrim)) { tv.tbest = t1; tv.bestPrim = i0 + k; }

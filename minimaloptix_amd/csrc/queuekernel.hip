@@ -630,17 +630,21 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
 
 }  // namespace
 
-int queuekernel_lds_stack_entries() { return kStackN; }
-int queuekernel_slots() { return kP; }
-size_t queuekernel_cold_bytes(int nBlocks) { return (size_t)nBlocks * kWaves * kP * sizeof(SlotCold); }
-size_t queuekernel_overflow_ints(int nBlocks, int ovfDepth) { return (size_t)nBlocks * kWaves * kP * (size_t)ovfDepth; }
+// queuekernel_lean.hip compiles this file a second time (other slot count, stack depth and occupancy target) under other names
+#ifndef PT_QK_EXPORT
+#define PT_QK_EXPORT(name) name
+#endif
+int PT_QK_EXPORT(queuekernel_lds_stack_entries)() { return kStackN; }
+int PT_QK_EXPORT(queuekernel_slots)() { return kP; }
+size_t PT_QK_EXPORT(queuekernel_cold_bytes)(int nBlocks) { return (size_t)nBlocks * kWaves * kP * sizeof(SlotCold); }
+size_t PT_QK_EXPORT(queuekernel_overflow_ints)(int nBlocks, int ovfDepth) { return (size_t)nBlocks * kWaves * kP * (size_t)ovfDepth; }
 
 template <bool CNT, bool FAST>
 static void launch_qk(dim3 grid, dim3 block, hipStream_t stream, const LaunchArgs& a) {
   if (a.scene.shadowNearest) pt_queuekernel<CNT, true, FAST, true><<<grid, block, 0, stream>>>(a);
   else                       pt_queuekernel<CNT, true, FAST, false><<<grid, block, 0, stream>>>(a);
 }
-hipError_t launch_queuekernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading) {
+hipError_t PT_QK_EXPORT(launch_queuekernel)(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading) {
   dim3 grid(nBlocks), block(kBlockThreads);
   // fastShading: opt-in approximate BRDF arithmetic (pt_disney.h ShadeMath)
   if (fastShading) { if (counted) launch_qk<true, true>(grid, block, stream, a); else launch_qk<false, true>(grid, block, stream, a); }
