@@ -31,8 +31,8 @@ namespace {
 
 constexpr int kBlockThreads = 256;
 constexpr int kWaves = kBlockThreads / 64;
-// Path slots per wave and LDS stack entries per slot: what a workgroup's third of the CU's LDS (54,592 bytes for three workgroups,
-// tools/micro/lds_limit.hip) is spent on.  A slot costs 32 B of ray + 4 (entries + 1) B of stack + 12 B of ring space.  Measured on
+// Path slots per wave and LDS stack entries per slot: what a workgroup's third of the CU's LDS (53,760 bytes for three workgroups:
+// 42 blocks of 1,280; a 54,128-byte build ran two per CU) is spent on.  A slot costs 32 B of ray + 4 (entries + 1) B of stack + 12 B of ring space.  Measured on
 // coffee at 64 spp, same bits (profiles/r04_slots.txt): 512 slots x 11 entries 95.3 ms, 544 x 10 93.8, 576 x 9 93.3, 608 x 8 93.9,
 // 640 x 7 94.5 -- more paths in flight against more stack entries spilled to HBM.  (queuekernel.hip keeps its own 512 x 11.)
 #ifndef PT_PK_KP
