@@ -27,11 +27,12 @@ def timing(kind, kw, res, spp):
         flops = st.analyticTests * (17.0 * nS + 20.0 * nQ) / max(1, nS + nQ)
         import bench
         v = bench.valu_ceilings(REPO)
-        p3, p8 = v["v_fma_f32"][3] * 0.128, v["v_fma_f32"][8] * 0.128      # measured: G v_fma_f32/s x 64 lanes x 2 flop (profiles/r04_valu_ceiling.txt)
+        w = 4 if ctx.get_option("kernel_variant_used") == 3 else 3      # scenes without triangles run the lean queue kernel: four workgroups per CU
+        p3, p8 = v["v_fma_f32"][w] * 0.128, v["v_fma_f32"][8] * 0.128      # measured: G v_fma_f32/s x 64 lanes x 2 flop (profiles/r04_valu_ceiling.txt)
         tf = flops / ms / 1e9
-        print("       %-16s FP32: %.3g primitive tests x %.1f flop = %.2f TFLOP/s = %.3f of the measured v_fma_f32 rate at the kernel's 3 waves per SIMD "
+        print("       %-16s FP32: %.3g primitive tests x %.1f flop = %.2f TFLOP/s = %.3f of the measured v_fma_f32 rate at the kernel's %d waves per SIMD "
               "(%.1f TFLOP/s), %.3f of the best measured (8 waves per SIMD, %.1f), %.3f of the 157.3 TFLOP/s spec" % (
-            kind, st.analyticTests, (17.0 * nS + 20.0 * nQ) / max(1, nS + nQ), tf, tf / p3, p3, tf / p8, p8, tf / 157.3), flush=True)
+            kind, st.analyticTests, (17.0 * nS + 20.0 * nQ) / max(1, nS + nQ), tf, tf / p3, w, p3, tf / p8, p8, tf / 157.3), flush=True)
     return ctx.resolve_rgb8(spp)
 parity("cornell_quads", {}, (256, 256), 4)
 parity("random_spheres", dict(iarg=497), (160, 90), 2)
