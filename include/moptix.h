@@ -217,8 +217,9 @@ int moptix_unpack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, const 
  * tuning knobs (none of them changes a bit of the image):
  *   "kernel_variant"   0 per-lane kernel, 3 path slots and queues shared by the workgroup (variants 1 and 2 of rounds 1-2 are gone),
  *                      4 = 3 with one shading visit per bounce (pt_packet.h; scenes with <= 3 lights, else 3 runs).
- *                      While it has not been set: 4 for launches of >= 1e6 samples and >= 16 seeds on scenes that are not
- *                      mostly glass ("auto_packet" = 0 turns that off), else 3; scenes without triangles: see "analytic_queue"
+ *                      While it has not been set: 4 for launches of >= 1e6 samples and >= 16 seeds ("auto_packet" = 0 turns that
+ *                      off), else 3; scenes without triangles: see "analytic_queue" (they run a lean instantiation of 3, four
+ *                      workgroups per CU)
  *   "builder"          1 binned-SAH topology over the Morton order (default), 0 Morton radix tree
  *   "node_format"      variant 4: the node record the trace kernel fetches -- 128 = four child boxes in binary32 (one L2 line), 64 =
  *                      the same boxes on a 256-step grid over the node's box, rounded outwards (half a line: 4 L1 look-ups per

@@ -322,9 +322,9 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   // its visits are the cheaper ones as well: whole frame 442 against 452 ms, dining room at 64 spp 162 against 193 ms.
   const bool packetOk = hasTris && a.scene.nLights <= 3 && !a.scene.anyDisneyAnalytic;
   const double nSamples = (double)a.nItems * (double)nSeeds;
-  // ... but only where hits have shadow rays to pack: a scene that is mostly glass (the 1.1 M-triangle glass knot of
-  // BASELINE config 5: 257 ms on variant 3, 283 on variant 4 at 64 spp) gets nothing from the packet and pays for its wider records
-  const bool autoPacket = nSamples >= 1.0e6 && nSeeds >= 16 && c->glassFaceShare <= 0.5;
+  // (until round 4 mostly-glass scenes stayed on variant 3: no shadow rays to pack, and variant 4's wider records cost 10 % there; with
+  // this round's leaf pass and routing the two are level on the glass knot -- 56.2 against 57.0 ms -- so the packet kernel serves both)
+  const bool autoPacket = nSamples >= 1.0e6 && nSeeds >= 16;
   const bool usePacket = packetOk && (c->optVariant == 4 || (!c->variantExplicit && c->optAutoPacket != 0 && autoPacket));
   const bool useQueue = !usePacket && (c->optVariant >= 3) && (hasTris || analyticQueue);
   const bool leanQueue = useQueue && !hasTris;      // scenes without triangles: queuekernel_lean.hip
@@ -593,6 +593,8 @@ int moptix_set_stream(moptix_context c, void* hipStream) {
 int moptix_set_params(moptix_context c, const moptix_params* p) {
   if (!c || !p) return fail(c, MOPTIX_ERR_INVALID, "null argument");
   if (p->width == 0 || p->height == 0) return fail(c, MOPTIX_ERR_INVALID, "zero-sized launch");
+  // the node step sorts entry distances by their bit patterns (pt_path.h ChildKey): distances are clamped to tmin, which must not be negative
+  if (!(p->rayEpsilonT >= 0.0f)) return fail(c, MOPTIX_ERR_INVALID, "rayEpsilonT must be >= 0");
   const bool resized = !c->haveParams || p->width != c->params.width || p->height != c->params.height;
   // the node format is chosen by walking the scene's own paths from THIS camera (choose_node_format): a new camera or frame
   // size asks again at the next render (two probe launches, ~2 ms; scenes without a tree or with "node_format" set skip it)
