@@ -23,7 +23,7 @@ for case in range(cases):
     ctx.load(hs); ctx.accum_clear(); ctx.render(seeds); ref = ctx.accum_read()
     opts = dict(kernel_variant=rng.choice([3, 3, 4, 4]), leaf_size=rng.choice([1, 2, 4, 8]), tile_major=rng.choice([0, 1, 2, 3, 3]),
                 swap_lanes=rng.choice([8, 24, 48]), starve_lanes=rng.choice([4, 16, 40]), blocks_per_cu=rng.choice([1, 2, 3]),
-                sample_buffer_mb=rng.choice([1, 8192]), builder=rng.choice([0, 1, 1]), slots_in_use=rng.choice([-1, -1, 300, 64, 448, 509]),
+                sample_buffer_mb=rng.choice([1, 8192]), builder=rng.choice([0, 1, 1]), slots_in_use=rng.choice([-1, -1, 300, 64, 448, 509, 575, 576]),
                 aux_depth=rng.choice([0, 1, 1, 2, 3, 16]), node_format=rng.choice([0, 64, 64, 128]))
     for k, v in opts.items():
         ctx.set_option(k, v)
