@@ -17,6 +17,15 @@
 // (see PoolLds::freeMask, SlotSink, store_flags / arrive_parks / aux_done).  A launch's tail is a handful of paths
 // walking the 256-bounce cap; this makes each of their bounces one dependent ray instead of up to four.
 //
+// What a pass touches (round 4):
+//   * a finished packet is routed by what its continuation hit (kShadeFlag): Disney triangle hits to Q_SHADE, whose batches run the
+//     Disney program on full waves, everything else to Q_GEN, whose visit also takes the next work item;
+//   * the leaf pass makes ONE memory round trip: triangle records only -- no hit row (a tie at exactly tbest reads it), no material
+//     (Tri48::shadow says what a triangle is to a shadow ray), the packet's next ray only where this ray can end;
+//   * shade batches and leaf passes read the launch arguments through fresh_args(): nothing of the scene sits in scalar
+//     registers while the node loop runs;
+//   * 576 path slots x 9 LDS stack entries per workgroup: rings sized exactly, 53,104 of the 53,760 bytes three workgroups per CU get.
+//
 // Limits (moptix_api.hip falls back to variant 3 otherwise): at most kPacketShadows lights, no Disney material on an
 // analytic primitive (shadow rays then need the brute-force lists at every ray start).
 #include <hip/hip_runtime.h>
@@ -241,7 +250,7 @@ struct SlotSink {
   SlotCold* cold; int slot; v4* nodeA; v4* nodeB; int (*stack)[kStackN + 1]; const PathState* ps; int root;
   int axp;                              // this path's three borrowed slots (10 bits each) or -1
   __device__ __forceinline__ void shadow(int j, v3 d, float tmax, v3 w, float inv) const {
-    SlotCold* cw = cold + slot;
+    SlotCold* cw = at32(cold, slot);
     slot_store(&cw->pend[j], mk4(w.x, w.y, w.z, inv));
     if (axp >= 0) {
       const int ax = (axp >> (kSlotBits * j)) & kSlotMask;
@@ -286,7 +295,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
   };
   auto q_pop = [&](int q, bool want) -> int {
     const unsigned long long m = __ballot(want);
-    const int n = min(__popcll(m), qCount[q]);
+    const int n = min((int)__popcll(m), qCount[q]);      // (int): min(long long, int) resolves to the double overload
     int slot = -1;
     if (want) { const int r = lane_rank(m); if (r < n) slot = W.queue[q][ring_wrap<NS>(qHead[q] + r)]; }
     qHead[q] = ring_wrap<NS>(qHead[q] + n);
@@ -455,7 +464,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       const bool isSwitch = node0 == kSwitchRef;
       const bool shadow = (fl & kShadowRay) != 0, hitValid = (fl & kHitValid) != 0;
       const int cur = fl_cur(fl);
-      const SlotCold* cs = cold + slot;
+      const SlotCold* cs = at32(cold, slot);
       // one round trip: the leaf's triangles and whichever row of the slot record this visit needs
       LeafChunk ch;
       leaf_fetch4(sc, isSwitch ? make_leaf_ref(0, 1) : node0, 0, ch);
@@ -502,12 +511,12 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
             // the verdict of the nearest any-hit surface so far and that surface's id (equal-t rule) travel in the att row
             if (tv.bestPrim != oldPrim) {
               nfl = (nfl & ~(3 << (kStatShift + 2 * cur))) | (2 << (kStatShift + 2 * cur));
-              slot_store(&cold[slot].att[cur], mk4(tv.att.x, tv.att.y, tv.att.z, i2f(tv.bestPrim))); PT_ROWS(3, 1);
+              slot_store(&at32(cold, slot)->att[cur], mk4(tv.att.x, tv.att.y, tv.att.z, i2f(tv.bestPrim))); PT_ROWS(3, 1);
             }
           } else if (tv.att.x != oldAtt.x || tv.att.y != oldAtt.y || tv.att.z != oldAtt.z) {
             const bool zero = tv.att.x == 0.f && tv.att.y == 0.f && tv.att.z == 0.f;      // disneyAnyHit on an opaque surface
             nfl = (nfl & ~(3 << (kStatShift + 2 * cur))) | ((zero ? 1 : 2) << (kStatShift + 2 * cur));
-            if (!zero) { slot_store(&cold[slot].att[cur], mk4(tv.att.x, tv.att.y, tv.att.z, 0.f)); PT_ROWS(3, 1); }
+            if (!zero) { slot_store(&at32(cold, slot)->att[cur], mk4(tv.att.x, tv.att.y, tv.att.z, 0.f)); PT_ROWS(3, 1); }
           }
         } else if (tv.bestPrim != oldPrim) {
           // most leaf visits find nothing nearer: the hit row is only written when it changed (primitive ids are unique, so a new
@@ -516,7 +525,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           bool keep = true;
           if (hitValid && tv.tbest == na.w) { const v4 held = slot_load(&cs->hit); PT_ROWS(2, 1); keep = !(f2i(held.y) < tv.bestPrim); }
           if (keep) {
-            slot_store(&cold[slot].hit, mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma)); PT_ROWS(3, 1);
+            slot_store(&at32(cold, slot)->hit, mk4(i2f(tv.bestTri), i2f(tv.bestPrim), tv.beta, tv.gamma)); PT_ROWS(3, 1);
             nfl = (nfl & ~kShadeFlag) | kHitValid | (tv.bestCls == SHADOW_OPAQUE ? kShadeFlag : 0);
           }
         }
@@ -562,7 +571,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     v3 att[kPacketShadows] = { mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f), mk3(1.f, 1.f, 1.f) };
     int axp = -1;                                      // the three slots this path has borrowed for its shadow rays (10 bits each), -1 = none
     if (have) {
-      const SlotCold* cs = cold + slot;
+      const SlotCold* cs = at32(cold, slot);
       const int fl = W.stack[slot][0];
       const bool hitValid = (fl & kHitValid) != 0;
       const int nSh = (fl >> kPendShift) & 3;          // 0 for a slot that waits for a work item (flags are cleared then)
@@ -582,7 +591,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           wp[i] = slot_load(&cs->pend[i]); PT_ROWS(0, 1);
           const int ax = (axp >> (kSlotBits * i)) & kSlotMask;                 // only used with hadAux
           const int stt = hadAux ? fl_stat(W.stack[ax][0], 0) : fl_stat(fl, i);
-          if (stt == 2) { wa[i] = hadAux ? slot_load(&cold[ax].att[0]) : slot_load(&cs->att[i]); PT_ROWS(0, 1); }
+          if (stt == 2) { wa[i] = hadAux ? slot_load(&at32(cold, ax)->att[0]) : slot_load(&cs->att[i]); PT_ROWS(0, 1); }
           else if (stt == 1) wa[i] = mk4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -640,7 +649,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBRun); }
     bool useAux = false;
     if (have) {
-      SlotCold* cw = cold + slot;
+      SlotCold* cw = at32(cold, slot);
       // borrowed slots go back when the path has ended (the lane may hold a new path's camera ray by now)
       if (axp >= 0 && !(ps.mode == M_TRACE && ps.depth >= a.auxDepth)) {
         for (int j = 0; j < kPacketShadows; j++) { const int ax = (axp >> (kSlotBits * j)) & kSlotMask; atomicOr(&W.freeMask[ax >> 5], 1u << (ax & 31)); }
@@ -754,7 +763,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       }
       if (nqCount > 0 && __ballot(ns < 0) != 0ull) {
         const unsigned long long m = __ballot(ns < 0);
-        const int n = min(__popcll(m), nqCount);
+        const int n = min((int)__popcll(m), nqCount);
         if (ns < 0) {
           const int r = lane_rank(m);
           if (r < n) {

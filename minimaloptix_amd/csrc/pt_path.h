@@ -351,7 +351,7 @@ PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, St
   int top = kTravDone;
   if constexpr (Stack::kFlat) top = st.peek_fast(tv.sp);      // the entry below the top, requested together with the node
   if constexpr (N64) {
-    const Node64 n = load_const(sc.nodes64 + tv.node);
+    const Node64 n = load_const(at32(sc.nodes64, tv.node));
     const float sx = n.sx * tv.inv.x, sy = n.sy * tv.inv.y, sz = n.sz * tv.inv.z;
     const float cx = fma_(n.ox, tv.inv.x, tv.noi.x), cy = fma_(n.oy, tv.inv.y, tv.noi.y), cz = fma_(n.oz, tv.inv.z, tv.noi.z);
     const bool bx = tv.inv.x < 0.f, by = tv.inv.y < 0.f, bz = tv.inv.z < 0.f;      // the same for every node of a ray
@@ -360,7 +360,7 @@ PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, St
     planes4q(bz ? n.q[5] : n.q[2], sz, cz, nz); planes4q(bz ? n.q[2] : n.q[5], sz, cz, fz);
     node_step_nearfar<CNT>(ps, tv, st, ct, nx, fx, ny, fy, nz, fz, n.ref[0], n.ref[1], n.ref[2], n.ref[3], top);
   } else {
-    const Node128 n = load_const(sc.nodes + tv.node);
+    const Node128 n = load_const(at32(sc.nodes, tv.node));
     float a[4], b[4];
     planes4(n.lox, tv.inv.x, tv.noi.x, a); planes4(n.hix, tv.inv.x, tv.noi.x, b);
     for (int c = 0; c < 4; c++) { nx[c] = fminf_(a[c], b[c]); fx[c] = fmaxf_(a[c], b[c]); }
@@ -385,7 +385,7 @@ PT_HD void leaf_fetch4(const SceneView& sc, int leafRef, int base, LeafChunk& ch
 #endif
   for (int j = 0; j < 4; j++) {
     const int k = base + j < count ? base + j : count - 1;
-    const Tri48 tpv = load_const(sc.tris + (first + k));
+    const Tri48 tpv = load_const(at32(sc.tris, first + k));
     const Tri48* tp = &tpv;
     ch.p0[j] = tp->p0; ch.e0[j] = tp->e0; ch.e1[j] = tp->e1; ch.mat[j] = tp->mat; ch.prim[j] = tp->prim; ch.shadow[j] = tp->shadow;
   }
@@ -515,8 +515,8 @@ PT_HD void hit_attributes(const SceneView& sc, const PathState& ps, const Trav& 
     h.front = ray_at(ps.o, ps.d, t); h.back = h.front;
     h.mat = q->mat;
   } else {
-    const Tri48 tpv = load_const(sc.tris + tv.bestTri);
-    const TriShade spv = load_const(sc.triShade + tv.bestTri);
+    const Tri48 tpv = load_const(at32(sc.tris, tv.bestTri));
+    const TriShade spv = load_const(at32(sc.triShade, tv.bestTri));
     const Tri48* tp = &tpv;
     const TriShade* sp = &spv;
     // both records are requested before either is used: one memory round trip, not two

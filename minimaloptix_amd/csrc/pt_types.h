@@ -41,6 +41,22 @@ PT_HD T load_const(const T* p) {
 #endif
 }
 template <class T> PT_HD T load_uniform(const T* p) { return load_const(p); }      // the index is the same in every lane of the wave
+// &table[index] with a 32-bit byte offset (every scene table is far below 4 GB): on the device the address is then the table's
+// base in scalar registers + one 32-bit vector offset -- one shift (or multiply) per gather instead of 64-bit address arithmetic.
+template <class T> PT_HD T* at32(T* table, int index) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(table) + (uint32_t)((uint32_t)index * (uint32_t)sizeof(T)));
+#else
+  return table + index;
+#endif
+}
+template <class T> PT_HD const T* at32(const T* table, int index) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(table) + (uint32_t)((uint32_t)index * (uint32_t)sizeof(T)));
+#else
+  return table + index;
+#endif
+}
 
 PT_HD int make_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
 PT_HD int leaf_first(int ref) { return (~ref) >> 3; }

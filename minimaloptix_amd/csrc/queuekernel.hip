@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
   };
   auto q_pop = [&](int q, bool want) -> int {
     const unsigned long long m = __ballot(want);
-    const int n = min(__popcll(m), qCount[q]);
+    const int n = min((int)__popcll(m), qCount[q]);
     int slot = -1;
     if (want) { const int r = lane_rank(m); if (r < n) slot = W.queue[q][(qHead[q] + r) & (RC - 1)]; }
     qHead[q] = (qHead[q] + n) & (RC - 1);
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
       }
       if (nqCount > 0 && __ballot(ns < 0) != 0ull) {
         const unsigned long long m = __ballot(ns < 0);
-        const int n = min(__popcll(m), nqCount);
+        const int n = min((int)__popcll(m), nqCount);
         if (ns < 0) {
           const int r = lane_rank(m);
           if (r < n) {
