@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
   auto make_stack = [&](int slot) {
     SlotStack st;
     st.lds = (lds_int*)&W.stack[slot][1];
-    st.ovf = ovfBase ? ovfBase + (size_t)slot * a.ovfDepth : nullptr;
+    st.ovf = ovfBase ? reinterpret_cast<int*>(reinterpret_cast<char*>(ovfBase) + (uint32_t)((uint32_t)slot * (uint32_t)a.ovfDepth * 4u)) : nullptr;      // 32-bit offset: a pool's overflow area is far below 4 GB
     return st;
   };
 

@@ -54,7 +54,7 @@ struct PacketSink {
 // Material.cu:172-221 for one hit, without the traces (ps.N, ps.V, ps.mat, ps.o set by on_result; ps.light == 0).
 template <bool CNT, bool FAST = false, class Sink = PacketSink>
 PT_HD void on_lights_packet(const SceneView& sc, PathState& ps, Packet& pk, Counters& ct, const Sink& sink) {
-  const DevMaterial m = load_const(sc.mats + ps.mat);
+  const DevMaterial m = load_const(at32(sc.mats, ps.mat));
   packet_clear(pk);
   const Onb onb = make_onb(ps.N);
   const DisneyView dv = disney_view<FAST>(m, onb, ps.V);      // shared by the evaluations of this hit (up to three lights + the bounce)

@@ -87,7 +87,7 @@ struct PathState {
 //   * otherwise the traversal keeps the nearest candidate like a radiance ray does (tbest shrinks, bestPrim for ties) and
 //     tv.att is the verdict of the nearest one so far -- shadow_candidate.
 PT_HD bool shadow_any_hit(const SceneView& sc, int mat, v3& att) {
-  const DevMaterial m = load_const(sc.mats + mat);
+  const DevMaterial m = load_const(at32(sc.mats, mat));
   if (m.kind != MAT_DISNEY) return false;                 // no any-hit program: does not occlude
   if (m.brdfType == BRDF_GLASS) { att = att * m.color; return false; }
   att = mk3(0.f, 0.f, 0.f);
@@ -95,7 +95,7 @@ PT_HD bool shadow_any_hit(const SceneView& sc, int mat, v3& att) {
 }
 PT_HD void shadow_candidate(const SceneView& sc, int mat, float t, int prim, float tmin, float& tbest, int& bestPrim, v3& att) {
   if (!potential(t, prim, tmin, tbest, bestPrim)) return;      // most candidates are not nearer: no material fetch for them
-  const DevMaterial m = load_const(sc.mats + mat);
+  const DevMaterial m = load_const(at32(sc.mats, mat));
   if (m.kind != MAT_DISNEY) return;
   tbest = t; bestPrim = prim;
   att = (m.brdfType == BRDF_GLASS) ? m.color : mk3(0.f, 0.f, 0.f);
@@ -105,14 +105,14 @@ PT_HD void shadow_candidate(const SceneView& sc, int mat, float t, int prim, flo
 // still read from the material table.
 PT_HD bool shadow_any_hit_tri(const SceneView& sc, int cls, int mat, v3& att) {
   if (cls == SHADOW_NONE) return false;
-  if (cls == SHADOW_GLASS) { att = att * load_const(&sc.mats[mat].color); return false; }
+  if (cls == SHADOW_GLASS) { att = att * load_const(&at32(sc.mats, mat)->color); return false; }
   att = mk3(0.f, 0.f, 0.f);
   return true;
 }
 PT_HD void shadow_candidate_tri(const SceneView& sc, int cls, int mat, float t, int prim, float tmin, float& tbest, int& bestPrim, v3& att) {
   if (cls == SHADOW_NONE || !potential(t, prim, tmin, tbest, bestPrim)) return;
   tbest = t; bestPrim = prim;
-  att = (cls == SHADOW_GLASS) ? load_const(&sc.mats[mat].color) : mk3(0.f, 0.f, 0.f);
+  att = (cls == SHADOW_GLASS) ? load_const(&at32(sc.mats, mat)->color) : mk3(0.f, 0.f, 0.f);
 }
 
 // 1/d for the slab planes.  A direction component below 1e-30 in magnitude is treated as +-1e-30 so that
@@ -525,7 +525,7 @@ PT_HD void hit_attributes(const SceneView& sc, const PathState& ps, const Trav& 
     const int hasNormals = sp->hasNormals;
     h.mat = tp->mat;
     h.texu = 0.f; h.texv = 0.f;
-    if (sc.triUV != nullptr && sc.mats[h.mat].albedoTex != 0) {               // Geometry.cu:141-148
+    if (sc.triUV != nullptr && at32(sc.mats, h.mat)->albedoTex != 0) {               // Geometry.cu:141-148
       const TriUV* up = sc.triUV + tp->prim;
       if (up->hasUV) {
         const float w0 = 1.f - tv.beta - tv.gamma;
@@ -566,7 +566,7 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
   cnt<CNT>(ct.closestHits); census<CNT>(ct, CR_HIT);
   HitAttr h;
   hit_attributes(sc, ps, tv, h);
-  const DevMaterial m = load_const(sc.mats + h.mat);
+  const DevMaterial m = load_const(at32(sc.mats, h.mat));
   if (m.kind == MAT_LIGHT) {                                    // light, Material.cu:238-240
     census<CNT>(ct, CR_LIGHT);
     ps.rad = ps.rad + ps.thr * m.emission;
@@ -623,7 +623,7 @@ PT_HD void on_result(const SceneView& sc, PathState& ps, const Trav& tv, Counter
 // wave.  Same formulas and the same RNG draw order as the reference's program.
 template <bool CNT, bool FAST = false>
 PT_HD void on_lights(const SceneView& sc, PathState& ps, Counters& ct) {
-  const DevMaterial m = load_const(sc.mats + ps.mat);
+  const DevMaterial m = load_const(at32(sc.mats, ps.mat));
   int choice = 0;                       // 0 nothing, 1 shadow ray towards a light, 2 BRDF bounce
   v3 L = mk3(0.f, 0.f, 1.f), H = mk3(0.f, 0.f, 1.f), emission = mk3(0.f, 0.f, 0.f);
   float lightDst = 0.f, lightPdf = 0.f;
