@@ -391,6 +391,8 @@ class GpuFrame:
 
     def parallelism(self):
         a, world = self.a, self.world
+        if world > 1 and os.environ.get("MOPTIX_RCCL_LIB"):
+            return "TEST PLUMBING: %d ranks on one device through %s (not RCCL, not a measurement)" % (world, os.path.basename(os.environ["MOPTIX_RCCL_LIB"]))
         if world == 1:
             par = "single GPU" if self.emu <= 1 else "EMULATION: rank 0 of a %d-way %s split on one GPU" % (self.emu, a.split)
         elif self.sample_split:
@@ -421,7 +423,12 @@ def run_rank(a, frame_cls=GpuFrame):
     # MOPTIX_BENCH_FORCE_DIST=1 brings the process group up for a single rank too (exercises init/barrier/all_reduce
     # on a 1-GPU box); the measured path is unchanged
     use_dist = world > 1 or os.environ.get("MOPTIX_BENCH_FORCE_DIST") == "1"
-    backend = frame_cls.backend
+    # MOPTIX_BENCH_BACKEND=gloo + MOPTIX_BENCH_DEVICE=0 (+ MOPTIX_RCCL_LIB=tests/rccl_loopback/...): N ranks of THIS code on a one-GPU box -- the
+    # control plane over gloo, every rank on one device, the frame's collective through the loop-back transport.  Test plumbing
+    # (tests/test_gpu_rccl_loopback.py): it exercises the N > 1 branches of this file, it measures nothing.
+    backend = os.environ.get("MOPTIX_BENCH_BACKEND", frame_cls.backend)
+    if "MOPTIX_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["MOPTIX_BENCH_DEVICE"])
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
