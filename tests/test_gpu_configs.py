@@ -499,3 +499,27 @@ def test_c2_random_spheres_full_size_properties(gpu_ctx):
         gpu_ctx.set_partition(0, 1); gpu_ctx.set_option("analytic_queue", -1)
     img = whole / spp
     assert img.min() >= 0.0 and img.max() <= 1.0 and (img.sum(axis=2) > 0).mean() > 0.99      # bg 0.2: no black pixels
+
+
+@pytest.mark.gpu
+def test_round4_options_and_guards(gpu_ctx):
+    """The read-only options of round 4 and the parameter guard behind the node step's key sort: path slots per workgroup, the counted
+    launch's timeline (span >= tail >= 0, both in microseconds), the communicator's size without a communicator, and rayEpsilonT >= 0
+    (entry distances are sorted by their bit patterns, which needs them non-negative: pt_path.h ChildKey)."""
+    assert gpu_ctx.get_option("path_slots") == 576 and gpu_ctx.get_option("comm_ranks") == 0
+    hs = M.HostScene("file:coffee", 320, 180)
+    gpu_ctx.set_option("kernel_variant", 4)
+    try:
+        gpu_ctx.load(hs); gpu_ctx.accum_clear()
+        st = gpu_ctx.render_counted(M.launch_seeds(4))
+        span, tail = gpu_ctx.get_option("counted_span_us"), gpu_ctx.get_option("counted_tail_us")
+        assert st.rays > 0 and span > 0 and 0 <= tail <= span, (span, tail)
+    finally:
+        gpu_ctx.set_option("kernel_variant", 3)
+    import ctypes
+    p = type(hs.params)()
+    ctypes.memmove(ctypes.byref(p), ctypes.byref(hs.params), ctypes.sizeof(p))
+    p.rayEpsilonT = -1e-3
+    with pytest.raises(M.MoptixError):
+        gpu_ctx.set_params(p)
+    gpu_ctx.set_params(hs.params)
