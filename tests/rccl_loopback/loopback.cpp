@@ -96,13 +96,13 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { munmap(p, sizeof(Segment)); delete c; return ncclSystemError; }
     std::this_thread::sleep_for(std::chrono::microseconds(100));
   }
+  if (rank == 0) shm_unlink(c->name);      // every rank has mapped it: the name can go now, so a rank that dies later leaks nothing in /dev/shm
   *comm = (ncclComm_t)c;
   return ncclSuccess;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   Comm* c = (Comm*)comm;
   if (!c) return ncclInvalidArgument;
-  if (c->rank == 0) shm_unlink(c->name);
   munmap(c->seg, sizeof(Segment));
   delete c;
   return ncclSuccess;
