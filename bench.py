@@ -532,7 +532,8 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     a = parse_args(argv)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # nothing has touched the GPU yet: device_count() reads the driver's list without initialising HIP
+        # device_count() may initialise the HIP runtime in this (parent) process.  That is harmless only because the workers
+        # are started as CHILD processes (launch_workers -> subprocess); never exec from here, and keep GPU work out of the parent
         import torch
         have = torch.cuda.device_count()
         if have < a.gpus:
