@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <functional>
 #include <omp.h>
 #include "../../minimaloptix_amd/csrc/pt_path.h"
 #include "../../minimaloptix_amd/csrc/pt_packet.h"
@@ -129,6 +130,7 @@ static void build_sah_topology(const std::vector<v3>& lo, const std::vector<v3>&
   }
 }
 
+static int g_debugPixel = getenv("HOSTSIM_DEBUG_PIXEL") ? atoi(getenv("HOSTSIM_DEBUG_PIXEL")) : -1;   // every ray of this pixel to stderr
 static int g_packet = 0;      // 1 = the per-bounce state machine of pt_packet.h (kernel variant 4) instead of the per-ray one
 static int g_builder = 1;     // 0 = Morton radix tree (Karras), 1 = binned SAH over the Morton order (device default)
 
@@ -332,6 +334,57 @@ int hostsim_build_bvh(const hostsim_scene* s, int leafSize, hostsim_bvh_out* out
   return 0;
 }
 
+
+// Debugging aid: where does a ray lose a triangle?  Prints, for every node on the way from the root to the leaf that holds
+// face `prim`, the slab test of the child that leads there (with tbest = tmax), then the triangle test itself.
+extern "C" int hostsim_debug_ray(const hostsim_scene* s, int leafSize, const float o[3], const float d[3], float tmin, int prim) {
+  HostScene hs; make_scene(*s, leafSize, hs);
+  const HostBVH& b = hs.bvh;
+  if (prim < 0) { prim = b.tris[-prim].prim; fprintf(stderr, "[hostsim] triangle record %d is face %d\n", -prim, prim); return prim; }   // record index -> face
+  std::vector<std::pair<int, int>> path, cur;      // (node, child)
+  bool found = false;
+  std::function<void(int)> walk = [&](int ref) {
+    if (found || ref == kEmptyRef) return;
+    if (ref < 0) {
+      for (int k = 0; k < leaf_count(ref); k++) if (b.tris[leaf_first(ref) + k].prim == prim) { found = true; path = cur; }
+      return;
+    }
+    for (int c = 0; c < 4 && !found; c++) { cur.push_back({ ref, c }); walk(b.nodes[ref].ref[c]); cur.pop_back(); }
+  };
+  walk(b.rootRef);
+  if (!found) { fprintf(stderr, "[hostsim] face %d is in no leaf\n", prim); return 1; }
+  const v3 ro = mk3(o[0], o[1], o[2]), rd = mk3(d[0], d[1], d[2]);
+  const v3 inv = mk3(slab_inv(rd.x), slab_inv(rd.y), slab_inv(rd.z)), noi = neg_o_inv(ro, inv);
+  for (auto& pc : path) {
+    const Node128& n = b.nodes[pc.first]; const int c = pc.second;
+    const float* lo[3] = { &n.lox.x, &n.loy.x, &n.loz.x }; const float* hi[3] = { &n.hix.x, &n.hiy.x, &n.hiz.x };
+    const float iv[3] = { inv.x, inv.y, inv.z }, ni[3] = { noi.x, noi.y, noi.z };
+    float tn = tmin, tf = 3e38f;
+    fprintf(stderr, "[hostsim] node %d child %d ref %d:", pc.first, c, n.ref[c]);
+    for (int a = 0; a < 3; a++) {
+      const float t0 = fma_(lo[a][c], iv[a], ni[a]), t1 = fma_(hi[a][c], iv[a], ni[a]);
+      tn = fmaxf_(tn, fminf_(t0, t1)); tf = fminf_(tf, fmaxf_(t0, t1));
+      fprintf(stderr, "  [%.9g %.9g] t %.9g %.9g", lo[a][c], hi[a][c], t0, t1);
+    }
+    fprintf(stderr, "  -> tn %.9g tf %.9g %s\n", tn, tf, tn <= tf * 1.0000005f ? "entered" : "CULLED");
+  }
+  for (const Tri48& tr : b.tris) if (tr.prim == prim) {
+    v3 n; float t, be, ga;
+    const bool hit = tri_test(ro, rd, tmin, 1e27f, tr.p0, tr.e0, tr.e1, n, t, be, ga);
+    const v3 p1 = tr.p0 + tr.e0, p2 = tr.p0 - tr.e1;
+    fprintf(stderr, "[hostsim] face %d: p0 %.9g %.9g %.9g p1 %.9g %.9g %.9g p2 %.9g %.9g %.9g\n  float: %s t %.9g beta %.9g gamma %.9g n.d %.9g\n", prim, tr.p0.x, tr.p0.y, tr.p0.z,
+            p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, hit ? "HIT" : "miss", t, be, ga, dot(n, rd));
+    // the same formulas in double
+    const double O[3] = { ro.x, ro.y, ro.z }, D[3] = { rd.x, rd.y, rd.z }, P0[3] = { tr.p0.x, tr.p0.y, tr.p0.z }, E0[3] = { tr.e0.x, tr.e0.y, tr.e0.z }, E1[3] = { tr.e1.x, tr.e1.y, tr.e1.z };
+    auto crs = [](const double* a, const double* b2, double* c) { c[0] = a[1] * b2[2] - a[2] * b2[1]; c[1] = a[2] * b2[0] - a[0] * b2[2]; c[2] = a[0] * b2[1] - a[1] * b2[0]; };
+    auto dt = [](const double* a, const double* b2) { return a[0] * b2[0] + a[1] * b2[1] + a[2] * b2[2]; };
+    double N[3]; crs(E1, E0, N);
+    const double nd = dt(N, D); double E2[3] = { (P0[0] - O[0]) / nd, (P0[1] - O[1]) / nd, (P0[2] - O[2]) / nd }, I[3]; crs(D, E2, I);
+    fprintf(stderr, "  double: t %.12g beta %.12g gamma %.12g n.d %.12g\n", dt(N, E2), dt(I, E1), dt(I, E0), nd);
+  }
+  return 0;
+}
+
 // counters: samples, primary, bounce, shadow, nodeFetches, triTests, closestHits, lightLoads, analyticTests
 // timing (may be NULL): [0] seconds of scene set-up + LBVH build (single thread), [1] seconds of rendering (all OpenMP
 // threads), [2] the number of threads used -- bench.py's cpu_baseline: "a CPU build of the same megakernel", BVH build
@@ -382,6 +435,9 @@ int hostsim_render_timed(const hostsim_scene* s, int leafSize, const int32_t* se
         } else if (ps.mode == M_TRACE) {
           trav_begin<true>(sc, ps, tv, ct);
           while (tv.node != kTravDone) host_trav_step(sc, ps, tv, st, ct);
+          if (pix == g_debugPixel)
+            fprintf(stderr, "[hostsim] pixel %d depth %d kind %d o %.9g %.9g %.9g d %.9g %.9g %.9g tmin %.9g tmax %.9g -> t %.9g prim %d tri %d att %.9g %.9g %.9g\n", pix, ps.depth,
+                    (int)ps.kind, ps.o.x, ps.o.y, ps.o.z, ps.d.x, ps.d.y, ps.d.z, ps.tmin, ps.tmax, tv.tbest, tv.bestPrim, tv.bestTri, tv.att.x, tv.att.y, tv.att.z);
           ps.mode = M_RESULT;
         } else if (ps.mode == M_RESULT && g_packet) {
           on_result_packet<true>(sc, ps, pk, tv, att, ct, PacketSink{ pk });
