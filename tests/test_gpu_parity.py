@@ -351,9 +351,9 @@ def test_randomised_option_combinations_match_variant0():
     size, work order, thresholds, workgroups per CU, multi-pass sample buffer) against the per-lane kernel."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CASES="10", SEED="7")
+    env = dict(os.environ, CASES="40", SEED="7")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py")], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "mismatches: 0 " in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]      # (tree-dependent grazing hits are counted apart: DESIGN.md section 2)
 
 
 @pytest.mark.gpu
