@@ -1,0 +1,41 @@
+"""The product path against the oracle on random inputs: scene kind, frame size, sample count, seeds, shadow rule; default kernel
+choice.  Per case: RMSE of the per-sample mean (bar: 2e-6, the arithmetic contract's; north star: 1e-3), and the counts of rays and
+closest hits, which must be EQUAL -- one path decision taken differently anywhere in the frame shows there.
+SEED, CASES as tools/gpu_fuzz.py."""
+import os, sys, random, time
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from common import M, O, oracle_scene, rmse   # noqa: E402
+ctx = M.Context(0)
+rng = random.Random(int(os.environ.get("SEED", "1")))
+cases = int(os.environ.get("CASES", "24"))
+bad = 0; worst = 0.0
+default_variant = ctx.get_option("kernel_variant")
+for case in range(cases):
+    w, h = rng.choice([(64, 36), (101, 37), (200, 112), (160, 90), (33, 129), (8, 8), (240, 135)])
+    spp = rng.choice([1, 2, 3, 5])
+    scene = rng.choice(["file:coffee", "file:coffee", "dining_standin", "coffee_pot_standin", "million_standin", "random_spheres", "cornell_quads", "spheres"])
+    kw = dict(iarg=2) if scene == "dining_standin" else dict(iarg=rng.choice([3000, 40000])) if scene == "million_standin" else \
+        dict(iarg=rng.choice([97, 497])) if scene == "random_spheres" else dict(farg=rng.choice([0.0, 0.1, 0.5])) if scene == "spheres" else {}
+    rule = rng.choice([1, 1, 0])
+    seed0 = rng.randrange(100000)
+    hs = M.HostScene(scene, w, h, **kw)
+    seeds = M.launch_seeds(spp, seed0)
+    ctx.set_option("shadow_rule", rule)
+    ctx.set_option("kernel_variant", rng.choice([default_variant, 3, 4, 4]))      # the library's own choice, or one of the two schedulers
+    ctx.load(hs); ctx.accum_clear(); st = ctx.render_counted(seeds)
+    g = ctx.accum_read()[..., :3]
+    O.set_option("shadow_any_opaque_blocks", 1 if rule == 0 else 0)
+    t0 = time.time()
+    o, ost = oracle_scene(hs).render(seeds)
+    O.set_option("shadow_any_opaque_blocks", 0)
+    e = rmse(g / spp, o / spp)
+    ok = e <= 2e-6 and st.rays == ost.rays and st.closestHits == ost.closestHits
+    worst = max(worst, e)
+    print("case %3d %-18s %s %dx%d spp %d seed0 %d rule %d ran (%d, %d): rmse %.2e rays %d / %d closest hits %d / %d oracle %.1fs -> %s" % (
+        case, scene, kw, w, h, spp, seed0, rule, ctx.get_option("kernel_variant_used"), ctx.get_option("node_format_used"), e, st.rays, ost.rays,
+        st.closestHits, ost.closestHits, time.time() - t0, "ok" if ok else "MISMATCH"), flush=True)
+    bad += 0 if ok else 1
+print("cases %d mismatches %d worst rmse %.2e" % (cases, bad, worst))
+sys.exit(1 if bad else 0)
