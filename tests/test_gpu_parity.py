@@ -356,6 +356,16 @@ def test_randomised_option_combinations_match_variant0():
     assert r.returncode == 0 and "mismatches: 0 " in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]      # (tree-dependent grazing hits are counted apart: DESIGN.md section 2)
 
 
+def test_random_inputs_match_the_oracle_ray_for_ray():
+    """tools/gpu_oracle_fuzz.py: random scene kinds, frame sizes, sample counts, seeds, shadow rules and kernel variants through the
+    C ABI against the oracle: RMSE <= 2e-6 and EQUAL counts of rays and closest hits (profiles/r04_oracle_fuzz.txt: 1,200 cases)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CASES="32", SEED="9")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_oracle_fuzz.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 3, 4])
 @pytest.mark.parametrize("glass_below", [True, False])
