@@ -272,7 +272,7 @@ class GpuFrame:
         # milliseconds are a drain in which a few deep paths finish while most of the GPU idles.  Two contexts render
         # alternate frames on their own streams; every frame is still completed and gathered inside the timed region.
         # Measured +8 % on an emulated 8-way share of one GPU, never run beside RCCL kernels on a real multi-GPU node.
-        self.pipeline = (self.part_n > 1) and os.environ.get("MOPTIX_BENCH_PIPELINE", "0") == "1"
+        self.pipeline = os.environ.get("MOPTIX_BENCH_PIPELINE", "0") == "1"
         self.ctxs, self.accums = [self.ctx], [self.accum]
         if self.pipeline:
             ctx2 = M.Context(local)

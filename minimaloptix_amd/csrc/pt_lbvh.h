@@ -127,7 +127,10 @@ PT_HD float half_area(const float* lo, const float* hi) {
 //   * nodes are numbered breadth first, children in range order.
 // min / max / counts are exact and the sweep is one sequential function, so the tree is a pure function of the
 // input: tests/hostsim runs the same functions on the host and the GPU tests compare the trees word for word.
-constexpr int kSahBins = 16;
+#ifndef PT_SAH_BINS
+#define PT_SAH_BINS 16
+#endif
+constexpr int kSahBins = PT_SAH_BINS;
 constexpr int kSahLevels = 40;         // deeper levels split in the middle: bounds the depth at 40 + log2(n) <= 64 (wide_level's path)
 struct SahBins {                       // per axis and bin: box of the triangles (order-preserving uints) + their number
   uint32_t lo[3][kSahBins][3], hi[3][kSahBins][3];

@@ -345,6 +345,18 @@ PT_HD void planes4q(uint32_t w, float step, float base, float out[4]) {
   out[0] = fma_((float)(w & 0xffu), step, base); out[1] = fma_((float)((w >> 8) & 0xffu), step, base);
   out[2] = fma_((float)((w >> 16) & 0xffu), step, base); out[3] = fma_((float)(w >> 24), step, base);
 }
+// the step for a 64-byte record
+template <bool CNT, class Stack>
+PT_HD void trav_node_step64(const Node64& n, const PathState& ps, Trav& tv, Stack& st, Counters& ct, int top) {
+  float nx[4], fx[4], ny[4], fy[4], nz[4], fz[4];
+  const float sx = n.sx * tv.inv.x, sy = n.sy * tv.inv.y, sz = n.sz * tv.inv.z;
+  const float cx = fma_(n.ox, tv.inv.x, tv.noi.x), cy = fma_(n.oy, tv.inv.y, tv.noi.y), cz = fma_(n.oz, tv.inv.z, tv.noi.z);
+  const bool bx = tv.inv.x < 0.f, by = tv.inv.y < 0.f, bz = tv.inv.z < 0.f;      // the same for every node of a ray
+  planes4q(bx ? n.q[3] : n.q[0], sx, cx, nx); planes4q(bx ? n.q[0] : n.q[3], sx, cx, fx);
+  planes4q(by ? n.q[4] : n.q[1], sy, cy, ny); planes4q(by ? n.q[1] : n.q[4], sy, cy, fy);
+  planes4q(bz ? n.q[5] : n.q[2], sz, cz, nz); planes4q(bz ? n.q[2] : n.q[5], sz, cz, fz);
+  node_step_nearfar<CNT>(ps, tv, st, ct, nx, fx, ny, fy, nz, fz, n.ref[0], n.ref[1], n.ref[2], n.ref[3], top);
+}
 template <bool CNT, bool N64 = false, class Stack>
 PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, Stack& st, Counters& ct) {
   float nx[4], fx[4], ny[4], fy[4], nz[4], fz[4];
@@ -352,14 +364,32 @@ PT_HD void trav_node_step(const SceneView& sc, const PathState& ps, Trav& tv, St
   if constexpr (Stack::kFlat) top = st.peek_fast(tv.sp);      // the entry below the top, requested together with the node
   if constexpr (N64) {
     const Node64 n = load_const(at32(sc.nodes64, tv.node));
-    const float sx = n.sx * tv.inv.x, sy = n.sy * tv.inv.y, sz = n.sz * tv.inv.z;
-    const float cx = fma_(n.ox, tv.inv.x, tv.noi.x), cy = fma_(n.oy, tv.inv.y, tv.noi.y), cz = fma_(n.oz, tv.inv.z, tv.noi.z);
-    const bool bx = tv.inv.x < 0.f, by = tv.inv.y < 0.f, bz = tv.inv.z < 0.f;      // the same for every node of a ray
-    planes4q(bx ? n.q[3] : n.q[0], sx, cx, nx); planes4q(bx ? n.q[0] : n.q[3], sx, cx, fx);
-    planes4q(by ? n.q[4] : n.q[1], sy, cy, ny); planes4q(by ? n.q[1] : n.q[4], sy, cy, fy);
-    planes4q(bz ? n.q[5] : n.q[2], sz, cz, nz); planes4q(bz ? n.q[2] : n.q[5], sz, cz, fz);
-    node_step_nearfar<CNT>(ps, tv, st, ct, nx, fx, ny, fy, nz, fz, n.ref[0], n.ref[1], n.ref[2], n.ref[3], top);
+    trav_node_step64<CNT>(n, ps, tv, st, ct, top);
   } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Near / far plane per axis chosen by the ADDRESS the plane vector is fetched from: with d > 0 the lower planes of the four
+    // boxes are the ones the ray meets first (record offset 0 / 16 / 32), with d < 0 the upper ones (+48); fma is monotone in the
+    // plane, so this is exactly min / max of the two distances.  Six address additions (2.35-clock class; the six offsets are
+    // loop-invariant and live in registers) instead of 24 v_min / v_max (4.3): coffee 81.5 -> 78.9 ms at 64 spp on the packet
+    // kernel, same bits (round 5).  The 64-byte form keeps its lead (76.8 ms) although it issues 36 instructions more per step:
+    // a wave's seven gathers are served one after the other by the CU's address unit (64 lanes each), and that time is on the
+    // step's critical path (NOTEBOOK.md, round 5).  The host build keeps the plain form below (same values).
+    const char* nb = reinterpret_cast<const char*>(sc.nodes);
+    const uint32_t no = (uint32_t)tv.node * (uint32_t)sizeof(Node128);
+    const uint32_t sx = (uint32_t)(f2i(tv.inv.x) >> 31) & 48u, sy = (uint32_t)(f2i(tv.inv.y) >> 31) & 48u, sz = (uint32_t)(f2i(tv.inv.z) >> 31) & 48u;
+    const v4 pnx = load_const(reinterpret_cast<const v4*>(nb + (no + sx)));
+    const v4 pfx = load_const(reinterpret_cast<const v4*>(nb + (no + (48u - sx))));
+    const v4 pny = load_const(reinterpret_cast<const v4*>(nb + (no + (16u + sy))));
+    const v4 pfy = load_const(reinterpret_cast<const v4*>(nb + (no + (64u - sy))));
+    const v4 pnz = load_const(reinterpret_cast<const v4*>(nb + (no + (32u + sz))));
+    const v4 pfz = load_const(reinterpret_cast<const v4*>(nb + (no + (80u - sz))));
+    const i4r rf = load_const(reinterpret_cast<const i4r*>(nb + (no + 96u)));
+    planes4(pnx, tv.inv.x, tv.noi.x, nx); planes4(pfx, tv.inv.x, tv.noi.x, fx);
+    planes4(pny, tv.inv.y, tv.noi.y, ny); planes4(pfy, tv.inv.y, tv.noi.y, fy);
+    planes4(pnz, tv.inv.z, tv.noi.z, nz); planes4(pfz, tv.inv.z, tv.noi.z, fz);
+    node_step_nearfar<CNT>(ps, tv, st, ct, nx, fx, ny, fy, nz, fz, rf.x, rf.y, rf.z, rf.w, top);
+    return;
+#endif
     const Node128 n = load_const(at32(sc.nodes, tv.node));
     float a[4], b[4];
     planes4(n.lox, tv.inv.x, tv.noi.x, a); planes4(n.hix, tv.inv.x, tv.noi.x, b);

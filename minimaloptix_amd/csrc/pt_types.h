@@ -58,6 +58,8 @@ template <class T> PT_HD const T* at32(const T* table, int index) {
 #endif
 }
 
+struct alignas(16) i4r { int x, y, z, w; };      // four child references as one 16-byte load
+
 PT_HD int make_leaf_ref(int first, int count) { return ~((first << 3) | (count - 1)); }
 PT_HD int leaf_first(int ref) { return (~ref) >> 3; }
 PT_HD int leaf_count(int ref) { return ((~ref) & 7) + 1; }

@@ -38,7 +38,7 @@ class HostsimBvhOut(C.Structure):
 def hostsim_lib():
     global _hostsim
     if _hostsim is None:
-        path = os.path.join(_HOSTSIM_DIR, "libhostsim.so")
+        path = os.environ.get("HOSTSIM_LIB", os.path.join(_HOSTSIM_DIR, "libhostsim.so"))
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", _HOSTSIM_DIR, "-s"])
         L = C.CDLL(path)

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 // id, name, asm text.  Operands: %0 accumulator (read + written), %1 %2 two more vector registers, %3 an SGPR pair.
@@ -82,7 +83,21 @@
   X(66, "cmp(vcc)+2cndmask_indep[3]", "v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 v40, %0, %2, vcc\n v_cndmask_b32 v41, %2, %0, vcc") \
   X(67, "cmp_e64(s)+2cndmask_e64_indep[3]", "v_cmp_lt_f32_e64 s[20:21], %0, %1\n v_cndmask_b32_e64 v40, %0, %2, s[20:21]\n v_cndmask_b32_e64 v41, %2, %0, s[20:21]") \
   X(68, "v_cndmask_b32(vcc,literal0)", "v_cndmask_b32 %0, 0, %0, vcc") \
-  X(69, "v_addc_co_u32(vcc)", "v_addc_co_u32 %0, vcc, %0, %1, vcc")
+  X(69, "v_addc_co_u32(vcc)", "v_addc_co_u32 %0, vcc, %0, %1, vcc") \
+  X(70, "v_fma_mix_f32(f16lo,f32,f32)", "v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]") \
+  X(71, "v_fma_mix_f32(f16hi,f32,f32)", "v_fma_mix_f32 %0, %0, %1, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]") \
+  X(72, "v_cvt_f32_f16", "v_cvt_f32_f16 %0, %0") \
+  X(73, "v_ashrrev_i32", "v_ashrrev_i32 %0, 3, %0") \
+  X(74, "v_sub_u32", "v_sub_u32 %0, %0, %1") \
+  X(75, "v_or3_b32", "v_or3_b32 %0, %0, %1, %2") \
+  X(76, "v_xad_u32", "v_xad_u32 %0, %0, %1, %2") \
+  X(77, "v_mul_u32_u24", "v_mul_u32_u24 %0, %0, %1") \
+  X(78, "v_sad_u32", "v_sad_u32 %0, %0, %1, %2") \
+  X(79, "v_cvt_f32_i32", "v_cvt_f32_i32 %0, %0") \
+  X(80, "v_pk_max_f16", "v_pk_max_f16 %0, %0, %1") \
+  X(81, "v_pk_fma_f16", "v_pk_fma_f16 %0, %0, %1, %2") \
+  X(82, "v_mul_legacy_f32", "v_mul_legacy_f32 %0, %0, %1") \
+  X(83, "v_cmp_le_f32_e64(sgpr)+s_and", "v_cmp_le_f32_e64 s[20:21], %0, %1\n s_and_b64 s[22:23], s[20:21], s[20:21]")
 // 64-bit accumulators (register pairs)
 #define KINDS64(X) \
   X(100, "v_pk_fma_f32", "v_pk_fma_f32 %0, %0, %1, %2") \
@@ -154,6 +169,7 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0);
   const int cus = prop.multiProcessorCount;
   const int iters = argc > 1 ? atoi(argv[1]) : 10000;       // x 64 asm statements per iteration
+  const char* only = argc > 2 ? argv[2] : nullptr;          // run only the rows whose name contains this
   const int maxWaves = 8;
   unsigned long long* dStamps; float* dOut;
   (void)hipMalloc(&dStamps, sizeof(unsigned long long) * 2 * (size_t)cus * maxWaves * 4); (void)hipMalloc(&dOut, 64);
@@ -164,6 +180,7 @@ int main(int argc, char** argv) {
   printf("# instruction waves_per_SIMD ms G_statements_per_s cycles_per_statement_per_SIMD shader_clock_GHz\n");
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (const Entry& en : entries) {
+    if (only && !strstr(en.name, only)) continue;
     for (int w : { 1, 2, 3, 4, 8 }) {
       const int blocks = cus * w;
       const size_t ldsBytes = (size_t)(160 * 1024 / w) - 1024;      // n workgroups per CU: each asks for 1/n of the CU's LDS
