@@ -120,11 +120,12 @@ def cpu_baseline(width, height, target_s):
                       "launches, %.1f s, %d rays; LBVH build %.2f s on one thread excluded" % (width, height, n, secs, rays, build_s)}
 
 
-def read_traffic(repo):
+def read_traffic(repo, tag=None):
     """Counters of the trace kernel from the committed rocprofv3 PMC passes (collected separately: profiles/README.md,
-    tools/prof_bench.sh + tools/make_traffic_json.py).  Only used when they were collected on THIS device code
-    (source_hash); otherwise the fields are null rather than stale."""
-    p = os.path.join(repo, "profiles", "traffic.json")
+    tools/prof_bench.sh + tools/make_traffic_json.py; tag = "c2" / "c4" / "c5": the passes of that BASELINE config,
+    profiles/r05_traffic_<tag>.json).  Only used when they were collected on THIS device code (source_hash); otherwise the
+    fields are null rather than stale."""
+    p = os.path.join(repo, "profiles", "traffic.json" if not tag else "r05_traffic_%s.json" % tag)
     try:
         t = json.load(open(p))
     except Exception:
@@ -134,13 +135,17 @@ def read_traffic(repo):
     return t
 
 
-def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per_ray, rays, reduce_ms, kernel, traffic, ceil, node_bytes=NODE_BYTES, vceil=None):
+def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per_ray, rays, reduce_ms, kernel, traffic, ceil, node_bytes=NODE_BYTES, vceil=None,
+                   waves_per_simd=KERNEL_WAVES_PER_SIMD, flops_per_launch=None):
     """The dominant kernel against its roofs.
 
     Head of the block (the contract's form): SURVEY 8(d)'s ALGORITHMIC bytes per launch / the launch duration measured here,
     against the HBM peak.  Those bytes are served by the XCDs' L2s and the Infinity Cache (what really crossed the fabric is
     `traffic` / `hbm_frac`, from the PMC passes), so the fraction says how much traversal work per second the kernel does in
-    the survey's currency, not that HBM is 0.9 busy.
+    the survey's currency, not that HBM is 0.9 busy: `algorithmic_frac_of_hbm` repeats it under its own name, and `binding` /
+    `binding_frac` name the unit the counters say limits the kernel (the vector ALUs' issue rate) and how busy it is.
+    A scene without triangles (BASELINE config 2; SURVEY 8(d): "FP32-VALU-bound -- report flops there, not bytes") gets the same
+    block headed by its FP32 rate against the measured v_fma_f32 rate (`flops_per_launch`).
 
     `valu_issue`: what the counters say binds the kernel -- the issue rate of the vector ALUs at the three waves per SIMD its
     registers and LDS allow.  achieved = SQ_INSTS_VALU per launch (PMC pass of THIS device code, profiles/traffic.json) / the
@@ -154,25 +159,44 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
     sq = (traffic.get("SQ") or {}) if traffic else {}
     valu = sq.get("SQ_INSTS_VALU")
     lanes = round(sq["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"]), 4) if sq.get("SQ_THREAD_CYCLES_VALU") and sq.get("SQ_ACTIVE_INST_VALU") else None
-    head = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-            "traffic": fabric_gb,
-            "achieved_source": "SURVEY 8(d) algorithmic bytes of one launch (counting launch of this run: %d B per node fetch, 48 per triangle test, 108 per closest "
-                               "hit, 72 per light record, 24 per pixel) / mean launch duration of the timed region (HIP events on the launch stream)" % node_bytes,
-            "kernel": kernel, "node_bytes": int(node_bytes), "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
-            "algorithmic_bytes_per_launch": int(bytes_per_launch), "bytes_per_ray": round(bytes_per_ray, 1)}
+    if flops_per_launch and vceil:
+        tf = flops_per_launch / launch_s / 1e12
+        fpeak = vceil["v_fma_f32"][waves_per_simd] * 0.128
+        head = {"bound": "valu_fp32", "achieved": round(tf, 2), "peak": round(fpeak, 1), "unit": "TFLOP/s", "frac": round(tf / fpeak, 4), "traffic": fabric_gb,
+                "achieved_source": "primitive tests of one launch (counting launch of this run) x flop per test (sphere 17, quad 20: csrc/pt_path.h trav_begin) / mean launch "
+                                   "duration of the timed region (HIP events on the launch stream)",
+                "peak_source": "%s: v_fma_f32 at the kernel's %d waves per SIMD x 64 lanes x 2 flop (measured; the 157.3 TFLOP/s of the data sheet assume 2.4 GHz and 2.0 clocks "
+                               "per instruction)" % (VALU_CEILING_FILE, waves_per_simd),
+                "frac_of_spec_157_TFLOPs": round(tf / 157.3, 4), "flops_per_launch": float(flops_per_launch)}
+    else:
+        head = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "traffic": fabric_gb,
+                "algorithmic_frac_of_hbm": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "achieved_source": "SURVEY 8(d) algorithmic bytes of one launch (counting launch of this run: %d B per node fetch, 48 per triangle test, 108 per closest "
+                                   "hit, 72 per light record, 24 per pixel) / mean launch duration of the timed region (HIP events on the launch stream)" % node_bytes,
+                "note": "head = the contract's form (algorithmic bytes against the HBM peak); those bytes are served by L2 / Infinity Cache -- what crossed the fabric is "
+                        "`traffic` (`hbm_frac` of the peak) -- so `frac` is NOT HBM utilisation; what limits the kernel is named in `binding`"}
+    head.update({"kernel": kernel, "node_bytes": int(node_bytes), "launch_ms": round(launch_ms, 3), "launches_timed": int(nlaunch),
+                 "algorithmic_bytes_per_launch": int(bytes_per_launch), "bytes_per_ray": round(bytes_per_ray, 1)})
     vi = None
     if valu and vceil:
         ach = valu / launch_s / 1e9
-        peak = vceil["v_fma_f32"][KERNEL_WAVES_PER_SIMD]
-        half = vceil["v_min_f32"][KERNEL_WAVES_PER_SIMD]
+        peak = vceil["v_fma_f32"][waves_per_simd]
+        half = vceil["v_min_f32"][waves_per_simd]
         vi = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s", "frac": round(ach / peak, 4),
-              "peak_source": "%s: v_fma_f32, %d waves per SIMD, 256 CUs (measured, includes the clock the chip holds under that load)" % (VALU_CEILING_FILE, KERNEL_WAVES_PER_SIMD),
+              "peak_source": "%s: v_fma_f32, %d waves per SIMD, 256 CUs (measured, includes the clock the chip holds under that load)" % (VALU_CEILING_FILE, waves_per_simd),
               "peak_half_rate_class": round(half, 1), "frac_of_half_rate_class": round(ach / half, 4),
               "peak_best_occupancy": round(max(vceil["v_fma_f32"].values()), 1),
               "instructions_per_ray": round(valu / max(1, rays), 2), "lane_utilisation": lanes,
               "useful_lane_frac": round(ach / peak * lanes, 4) if lanes else None,
               "valu_active_frac": traffic.get("valu_active_frac")}
     head["valu_issue"] = vi
+    # what the counters say limits this kernel: the vector ALUs.  binding_frac = share of all SIMD-cycles with a vector instruction in the pipe
+    # (SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x cycles), PMC pass of this device code); null until such a pass exists for this workload
+    head["binding"] = "valu_issue"
+    head["binding_frac"] = traffic.get("valu_active_frac") if traffic else None
+    head["binding_source"] = ("vector pipes busy (SQ_ACTIVE_INST_VALU, replayed from the committed PMC passes of this device code); issue rate against the measured "
+                              "ceiling in `valu_issue`; NOTEBOOK.md round 5 has the experiments that say neither look-ups nor bytes bind it")
     head.update({
         "gather_peak_GBps": round(gpeak, 1) if gpeak else None, "gather_frac": round(achieved_gbs / gpeak, 4) if gpeak else None,
         "gather_peak_source": GATHER_CEILING_FILE + " (tools/micro/gather.hip: dependent per-lane gathers of %d-B records, 3.1 MB table, best over occupancies)" % node_bytes,
@@ -199,6 +223,36 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
     return head
 
 
+# BASELINE.json configs other than the headline: scene kind -> (tag of its committed PMC passes, configs[] index, what it is)
+OTHER_CONFIGS = {"random_spheres": ("c2", 1, "random_spheres (analytic spheres + quads, NoAccel)"),
+                 "dining_standin": ("c4", 3, "dining-room stand-in (multi-mesh, Disney BRDF; the asset is absent upstream)"),
+                 "million_standin": ("c5", 4, "1 M-triangle glass knot stand-in (the asset is absent upstream)")}
+CONFIGS_FILE = os.path.join("profiles", "r05_configs.json")      # one bench.py line per BASELINE config (tools/r05_configs.sh)
+
+
+def workload_text(a):
+    if a.scene == "file:coffee":
+        return "coffee.obj LBVH build+traverse, %dx%d, %d spp (BASELINE.json configs[2])" % (a.width, a.height, a.spp)
+    tag, idx, what = OTHER_CONFIGS.get(a.scene, (None, None, a.scene))
+    return "%s, %dx%d, %d spp on ONE GPU%s" % (what, a.width, a.height, a.spp, " (BASELINE.json configs[%d]'s scene; parity case, not the headline)" % idx if idx is not None else "")
+
+
+def other_configs(repo):
+    """The committed bench.py lines of BASELINE configs 2, 4, 5 (profiles/r05_configs.json, written by tools/r05_configs.sh on MI355X):
+    their rates and roofline fractions ride along in the headline's block so that one line says what limits each kernel."""
+    try:
+        rows = json.load(open(os.path.join(repo, CONFIGS_FILE)))
+    except Exception:
+        return None
+    out = {}
+    for tag, d in rows.items():
+        r = d.get("roofline", {})
+        out[tag] = {"workload": d.get("config", {}).get("workload"), "value_Mrays_s": d.get("value"), "ms_per_step": d.get("ms_per_step"),
+                    "bound": r.get("bound"), "frac": r.get("frac"), "binding": r.get("binding"), "binding_frac": r.get("binding_frac"),
+                    "source_hash": d.get("config", {}).get("source_hash")}
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +262,7 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--scene", default="file:coffee")
+    ap.add_argument("--iarg", type=int, default=0, help="integer argument of a stand-in scene (dining_standin: copies, million_standin: triangles, random_spheres: spheres)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-leg", action="store_true", help="skip the untimed fast_shading comparison leg (PMC passes)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -247,7 +302,8 @@ class GpuFrame:
         self.device = torch.device("cuda", local)
         torch.cuda.set_device(local)
         self.ctx = M.Context(local)                 # raises when the HIP library / device is missing: no fallback
-        hs = M.HostScene(a.scene, a.width, a.height)
+        hs = M.HostScene(a.scene, a.width, a.height, iarg=a.iarg) if getattr(a, "iarg", 0) else M.HostScene(a.scene, a.width, a.height)
+        self.hs_sizes = (int(hs.sizes.nSpheres), int(hs.sizes.nQuads), int(hs.sizes.nFaces))
         # MOPTIX_BENCH_EMULATE_RANKS=n (single process only): render rank 0's share of an n-way tile split, to study a
         # rank's launch on a 1-GPU box; the JSON line then describes that share, not the frame
         self.emu = int(os.environ.get("MOPTIX_BENCH_EMULATE_RANKS", "0")) if world == 1 else 0
@@ -305,6 +361,9 @@ class GpuFrame:
         # the counting launch stamps its own timeline: first wave in -> last wave out, and how much of that came after the last work item
         self.counted_span_ms = self.ctx.get_option("counted_span_us") * 1e-3
         self.counted_tail_ms = self.ctx.get_option("counted_tail_us") * 1e-3
+        nS, nQ, nF = self.hs_sizes
+        # scenes without an acceleration structure are FP32-VALU bound -- flops, not bytes: primitive tests x flop per test
+        self.flops = float(st.analyticTests) * (17.0 * nS + 20.0 * nQ) / max(1, nS + nQ) if nF == 0 else None
         return st.rays, algorithmic_bytes(st, px, self.node_bytes)
 
     def collect(self, j):                                               # the frame's one collective
@@ -403,8 +462,14 @@ class GpuFrame:
 
     def traffic(self):
         a = self.a
-        if self.world == 1 and self.emu <= 1 and a.scene == "file:coffee" and (a.width, a.height, a.spp) == (1920, 1080, 256):
+        if self.world != 1 or self.emu > 1:
+            return None
+        if a.scene == "file:coffee" and (a.width, a.height, a.spp) == (1920, 1080, 256):
             return read_traffic(REPO)
+        if a.scene in OTHER_CONFIGS:                       # the PMC passes of tools/r05_configs.sh belong to one size per config
+            t = read_traffic(REPO, OTHER_CONFIGS[a.scene][0])
+            if t and t.get("workload") == workload_text(a):
+                return t
         return None
 
 
@@ -495,15 +560,22 @@ def run_rank(a, frame_cls=GpuFrame):
         passes_per_step = max(1, nlaunch // max(1, a.steps))
         achieved = my_bytes / passes_per_step / max(launch_ms * 1e-3, 1e-12) / 1e9        # GB/s, rank 0's trace kernel
         d = fr.describe()
+        lean = d.get("kernel_variant") == 3 and getattr(fr, "flops", None) is not None      # scenes without triangles: queuekernel_lean.hip, four workgroups per CU
         roof = roofline_block(achieved, launch_ms, nlaunch, my_bytes // passes_per_step, my_bytes / max(1, my_rays), my_rays,
-                              reduce_ms, d.pop("kernel"), fr.traffic(), gather_ceilings(REPO), getattr(fr, "node_bytes", NODE_BYTES), valu_ceilings(REPO))
+                              reduce_ms, d.pop("kernel"), fr.traffic(), gather_ceilings(REPO), getattr(fr, "node_bytes", NODE_BYTES), valu_ceilings(REPO),
+                              waves_per_simd=4 if lean else KERNEL_WAVES_PER_SIMD,
+                              flops_per_launch=(fr.flops / passes_per_step) if getattr(fr, "flops", None) else None)
+        headline = a.scene == "file:coffee" and (W, H, a.spp) == (1920, 1080, 256)
+        if headline and world == 1:
+            roof["other_configs"] = other_configs(REPO)      # BASELINE configs 2, 4, 5: their committed lines' rates and fractions
         out = {
-            "metric": "Mrays/s (primary+bounce+shadow rays traced per second, coffee.obj 1920x1080 256spp)",
+            "metric": "Mrays/s (primary+bounce+shadow rays traced per second, %s)" % ("coffee.obj 1920x1080 256spp" if headline else "%s %dx%d %dspp" % (a.scene, W, H, a.spp)),
             "value": round(total_rays / (dt / a.steps) / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": getattr(fr, "data", "reference scene scenes/coffee (168,193 triangles; Mesh010 missing upstream), synthetic seed schedule tea16(i,0)"),
-            "config": dict({"workload": "coffee.obj LBVH build+traverse, %dx%d, %d spp (BASELINE.json configs[2])" % (W, H, a.spp),
+            "data": getattr(fr, "data", "reference scene scenes/coffee (168,193 triangles; Mesh010 missing upstream), synthetic seed schedule tea16(i,0)" if a.scene == "file:coffee"
+                            else "stand-in scene authored by this project (minimaloptix_amd/host/standin_scenes.cpp, scenes.cpp), synthetic seed schedule tea16(i,0)"),
+            "config": dict({"workload": workload_text(a),
                             "scene": a.scene, "width": W, "height": H, "spp": a.spp, "rays_per_frame": int(total_rays),
                             "parallelism": fr.parallelism(), "split": a.split if world > 1 else None,
                             "pipeline": bool(getattr(fr, "pipeline", False)), "ms_per_frame": round(ms_per_step, 3),

@@ -29,6 +29,7 @@ extern "C" {
 #define MOPTIX_ERR_HIP           -3   /* HIP runtime error (text in last_error)     */
 #define MOPTIX_ERR_STATE         -4   /* call order (e.g. launch before build_accel)*/
 #define MOPTIX_ERR_LIMIT         -5   /* scene exceeds a compiled limit             */
+#define MOPTIX_ERR_COMM          -6   /* a collective did not complete (peer missing / communicator error); the communicator was aborted */
 
 typedef struct moptix_context_t* moptix_context;
 
@@ -191,7 +192,10 @@ int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
  *                         tiles and ncclSend()s them to dstRank, which receives them in one group and writes them into its
  *                         accuBuffer on the device: dstRank then holds the whole frame, bit-identical to a one-GPU render.
  *   moptix_reduce_frame : sample split -- ncclReduce(sum) of the accuBuffers into dstRank's.
- * Both block until the data has landed (stream-synchronised).  With a communicator of one rank they are no-ops.
+ * Both block until the data has landed -- at most "comm_timeout_ms" (option; default 120 s): a collective that has not completed
+ * by then (a peer died or never called), or whose communicator reports an asynchronous error, is ABORTED (ncclCommAbort) and the
+ * call returns MOPTIX_ERR_COMM; the host should exit (the context itself stays usable as a one-rank context).  With a
+ * communicator of one rank they are no-ops.
  * moptix_pack_tiles / moptix_unpack_tiles are the device-side halves of the gather (rank r's tiles of the accuBuffer <->
  * a dense buffer of moptix_packed_tile_floats(nRanks) floats in work-item order), exposed so that the partition can be
  * tested on one GPU. */
@@ -214,12 +218,16 @@ int moptix_unpack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, const 
  *                      demo/coffee.png with a stand-in for the missing pot; real Trbvh traversal is not strictly front
  *                      to back.  0: SURVEY A2's order-independent rule (the oracle's switch shadow_any_opaque_blocks).  The two differ
  *                      only in scenes with a Disney GLASS material (the benchmark scene has none); takes effect at the next render.
- * tuning knobs (none of them changes a bit of the image):
+ * tuning knobs.  The scheduler knobs (kernel_variant, slots_in_use, aux_depth, analytic_queue, tile_major, blocks_per_cu, swap_lanes,
+ * starve_lanes, exit_threshold, leaf_threshold, sample_buffer_mb) never change a bit of the image.  The tree-shaping knobs (builder,
+ * leaf_size, node_format) are bit-stable with ONE documented exception: the reference's float triangle test (Geometry.cu:121-160) can
+ * accept a grazing hit on a needle triangle at a point outside that triangle's own bounding box, and whether any traversal ever tests
+ * that triangle then depends on the boxes around it -- 1 pixel-sample in 3,600 fuzz cases (profiles/r04_fuzz.txt).
  *   "kernel_variant"   0 per-lane kernel, 3 path slots and queues shared by the workgroup (variants 1 and 2 of rounds 1-2 are gone),
- *                      4 = 3 with one shading visit per bounce (pt_packet.h; scenes with <= 3 lights, else 3 runs).
- *                      While it has not been set: 4 for launches of >= 1e6 samples and >= 16 seeds ("auto_packet" = 0 turns that
- *                      off), else 3; scenes without triangles: see "analytic_queue" (they run a lean instantiation of 3, four
- *                      workgroups per CU)
+ *                      4 = 3 with one shading visit per bounce (pt_packet.h; scenes with <= 3 lights, else 3 runs),
+ *                      -1 (default) = the library's choice per launch: 4 for launches of >= 1e6 samples and >= 16 seeds
+ *                      ("auto_packet" = 0 turns that off), else 3; scenes without triangles: see "analytic_queue" (they run a lean
+ *                      instantiation of 3, four workgroups per CU).  get_option returns -1 while the choice is the library's
  *   "builder"          1 binned-SAH topology over the Morton order (default), 0 Morton radix tree
  *   "node_format"      variant 4: the node record the trace kernel fetches -- 128 = four child boxes in binary32 (one L2 line), 64 =
  *                      the same boxes on a 256-step grid over the node's box, rounded outwards (half a line: 4 L1 look-ups per
@@ -246,6 +254,9 @@ int moptix_unpack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, const 
  *                      1: hardware reciprocal / square-root approximations there (the reference itself is built with
  *                      -use_fast_math, utils_host.cpp:30-32): same rays, BRDF weights within ~1e-6, default kernel only
  *   "watchdog_ms"      wall-clock bound of one render kernel (default 600000); a pass cut short is not accumulated
+ *   "comm_timeout_ms"  deadline of moptix_gather_tiles / moptix_reduce_frame (default 120000): when the collective has not completed by
+ *                      then, or the communicator reports an asynchronous error, the communicator is aborted and the call returns
+ *                      MOPTIX_ERR_COMM instead of blocking the rank for good
  * read-only (get_option): "kernel_variant_used", "node_format_used", "path_slots", "num_cus", "comm_ranks" (size of the context's
  *   communicator, 0 without one), and after moptix_render_counted
  *   "counted_span_us" (first wave in -> last wave out of the trace kernel) / "counted_tail_us" (the part of it after the last

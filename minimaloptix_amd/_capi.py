@@ -12,8 +12,8 @@ LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
 MOPTIX_OK = 0
-MOPTIX_ERR_INVALID, MOPTIX_ERR_NO_DEVICE, MOPTIX_ERR_HIP, MOPTIX_ERR_STATE, MOPTIX_ERR_LIMIT = -1, -2, -3, -4, -5
-ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_LIMIT = -1, -2, -3, -4, -5
+MOPTIX_ERR_INVALID, MOPTIX_ERR_NO_DEVICE, MOPTIX_ERR_HIP, MOPTIX_ERR_STATE, MOPTIX_ERR_LIMIT, MOPTIX_ERR_COMM = -1, -2, -3, -4, -5, -6
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_LIMIT, ERR_COMM = -1, -2, -3, -4, -5, -6
 MAT_LAMBERTIAN, MAT_METAL, MAT_GLASS, MAT_DISNEY, MAT_LIGHT = range(5)
 BRDF_NORMAL, BRDF_GLASS = 0, 1
 LIGHT_SPHERE, LIGHT_QUAD = 0, 1

@@ -2,6 +2,8 @@
 // Host-side staging of the scene, upload, LBVH build, launches, read-back, measurement.
 // There is no CPU path: every entry point that computes needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <thread>
 // RCCL's types and prototypes: from its header where there is one, else the handful this file needs (the library is bound at
 // run time by name, see load_rccl; a build box without the RCCL package -- or `make EXTRA=-DMOPTIX_NO_RCCL_HEADER` -- still
 // builds the whole library, and moptix_comm_* answer MOPTIX_ERR_STATE where no librccl can be loaded).
@@ -11,7 +13,7 @@
 extern "C" {
 typedef struct ncclComm* ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
-typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5 } ncclResult_t;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
 typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8 } ncclDataType_t;
 typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
 ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
@@ -23,6 +25,8 @@ ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int
 ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, int root, ncclComm_t comm, hipStream_t stream);
 ncclResult_t ncclGroupStart();
 ncclResult_t ncclGroupEnd();
+ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError);
+ncclResult_t ncclCommAbort(ncclComm_t comm);
 }
 #endif
 #include <rocprim/rocprim.hpp>
@@ -116,6 +120,7 @@ struct moptix_context_t {
   int optAutoPacket = 1;
   int lastVariant = -1;              // what the last render ran (get_option "kernel_variant_used")
   int countedSpanUs = -1, countedTailUs = -1;   // last counted launch: first wave in -> last wave out, and the part of it after the last work item was handed out
+  int optCommTimeoutMs = 120000;     // deadline of a collective's completion (comm_wait); the first collective of a communicator also sets its links up
   int optShadowRule = 1;             // 1 = a shadow ray is decided by its nearest any-hit surface (default), 0 = SURVEY A2's order-independent rule
   bool variantExplicit = false;      // kernel_variant was set by the caller: no automatic choice
   int optSlotsInUse = -1;            // -1 = chosen per launch from its size
@@ -181,8 +186,8 @@ void fill_view(moptix_context c, SceneView& v) {
 // room, 0.7 % for coffee) and synthetic rays miss this, so the scene is asked with its own paths: one sample per pixel of a
 // 128-pixel-wide grid over the camera's view, cut at depth 6, walked under both forms; the counts are priced with the per-step
 // costs fitted to coffee, the coffee pot, the glass knot and the dining room (round 4: a triangle test = 1.3 node steps of the
-// 128-byte form; a 64-byte step = 0.78 of one).  Decided at the first render after a build; a later change of
-// camera keeps the verdict.
+// 128-byte form; a 64-byte step = 0.78 of one).  Decided at the first render after a build or a change of frame size; a
+// later change of camera keeps the verdict (moptix_set_params).
 constexpr int kProbeWidth = 128;
 int choose_node_format(moptix_context c) {
   c->formatDecided = true;
@@ -493,6 +498,9 @@ struct RcclApi {
   decltype(&ncclCommDestroy) CommDestroy = nullptr; decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclSend) Send = nullptr; decltype(&ncclRecv) Recv = nullptr; decltype(&ncclReduce) Reduce = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  // optional (used by comm_wait when the library has them): error state of a communicator without blocking, and tearing one down
+  // while its kernels are still on the stream
+  decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr; decltype(&ncclCommAbort) CommAbort = nullptr;
   bool ok = false; std::string error;
 };
 // MOPTIX_RCCL_LIB names another library with the same nine entry points (a transport plug point; tests/rccl_loopback is a
@@ -517,6 +525,8 @@ RcclApi load_rccl() {
   api.Send = (decltype(api.Send))sym("ncclSend"); api.Recv = (decltype(api.Recv))sym("ncclRecv"); api.Reduce = (decltype(api.Reduce))sym("ncclReduce");
   api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart"); api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
   api.ok = all;
+  api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
+  api.CommAbort = (decltype(api.CommAbort))dlsym(h, "ncclCommAbort");
   return api;
 }
 RcclApi& rccl() {
@@ -528,6 +538,38 @@ int ncclFail(moptix_context c, ncclResult_t r, const char* what) {
 }
 #define RCCL_READY(c) do { if (!rccl().ok) return fail((c), MOPTIX_ERR_STATE, rccl().error); } while (0)
 #define NCCLCHK(c, x, what) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return ncclFail((c), r_, (what)); } while (0)
+
+// The end of a collective: wait for the context's stream WITH A DEADLINE.  A collective's kernels spin on the device until every
+// peer has joined; a peer that died or never calls leaves them spinning, and a bare hipStreamSynchronize would then block this
+// rank for good (only the CLI's --spawn parent has its own deadline).  So the stream is polled; each poll asks the communicator
+// for an asynchronous error (a peer's process gone, a link down); on an error or after "comm_timeout_ms" the communicator is
+// ABORTED (ncclCommAbort makes its kernels leave), the stream is given a bounded time to drain, and the call returns
+// MOPTIX_ERR_COMM: the host is expected to exit (bench.py, class MinimalOptiX and dist.py raise).  The context keeps working
+// as a one-rank context; a new communicator needs moptix_comm_init again.
+int comm_wait(moptix_context c, const char* what) {
+  using clock = std::chrono::steady_clock;
+  const auto t0 = clock::now();
+  const auto deadline = std::chrono::milliseconds(c->optCommTimeoutMs);
+  std::string why;
+  for (unsigned spin = 0;; spin++) {
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipSuccess) return MOPTIX_OK;
+    if (q != hipErrorNotReady) return hipFail(c, q, what);
+    ncclResult_t aerr = ncclSuccess;
+    if (c->comm && rccl().CommGetAsyncError && rccl().CommGetAsyncError(c->comm, &aerr) == ncclSuccess && aerr != ncclSuccess && aerr != ncclInProgress) {
+      why = std::string("communicator reports ") + rccl().GetErrorString(aerr); break;
+    }
+    if (clock::now() - t0 > deadline) { why = "no completion within comm_timeout_ms = " + std::to_string(c->optCommTimeoutMs) + " (a peer is missing or late)"; break; }
+    if (spin < 4096) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
+  }
+  if (c->comm) {
+    if (rccl().CommAbort) (void)rccl().CommAbort(c->comm); else (void)rccl().CommDestroy(c->comm);
+    c->comm = nullptr; c->commRank = 0; c->commRanks = 1;
+  }
+  const auto t1 = clock::now();                     // the aborted kernels leave; never wait for them without a bound either
+  while (hipStreamQuery(c->stream) == hipErrorNotReady && clock::now() - t1 < std::chrono::seconds(10)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  return fail(c, MOPTIX_ERR_COMM, std::string(what) + ": " + why + "; the communicator was aborted");
+}
 
 }  // namespace
 
@@ -600,9 +642,11 @@ int moptix_set_params(moptix_context c, const moptix_params* p) {
   // the node step sorts entry distances by their bit patterns (pt_path.h ChildKey): distances are clamped to tmin, which must not be negative
   if (!(p->rayEpsilonT >= 0.0f)) return fail(c, MOPTIX_ERR_INVALID, "rayEpsilonT must be >= 0");
   const bool resized = !c->haveParams || p->width != c->params.width || p->height != c->params.height;
-  // the node format is chosen by walking the scene's own paths from THIS camera (choose_node_format): a new camera or frame
-  // size asks again at the next render (two probe launches, ~2 ms; scenes without a tree or with "node_format" set skip it)
-  if (!c->haveParams || resized || memcmp(&p->cam, &c->params.cam, sizeof(p->cam)) != 0) c->formatDecided = false;
+  // The node format is chosen by walking the scene's own paths from the camera of the first render after a build
+  // (choose_node_format: a device allocation, two probe launches and a stream synchronisation).  A new frame size asks again; a
+  // new CAMERA alone does not: a moving camera (updateVideo, MinimalOptiX.cpp:761-778) would otherwise pay that blocking probe in
+  // every frame, inside moptix_render_async as well.  set_option("node_format", 0) asks again explicitly.
+  if (!c->haveParams || resized) c->formatDecided = false;
   c->params = *p; c->haveParams = true;
   if (resized && !c->accumBound) { c->accumPixels = 0; }
   return MOPTIX_OK;
@@ -762,7 +806,16 @@ int moptix_build_accel(moptix_context c, const char* kind) {
     for (int m : c->faceMat) glassFaces += (c->mats[m].kind == MAT_GLASS || (c->mats[m].kind == MAT_DISNEY && c->mats[m].brdfType == BRDF_GLASS)) ? 1 : 0;
     c->glassFaceShare = (double)glassFaces / (double)nFaces;
     HIPCHK(c, lbvh_build(c->stream, c->dFacePos.p, c->dFaceNrm.p, c->dFaceHasNrm.p, c->dFaceMat.p, nFaces, c->optLeafSize, c->optBuilder, &c->bvh), "LBVH build");
+    // The kernels address every scene table with a 32-bit byte offset from its base (pt_types.h at32) and a leaf reference holds
+    // its first record in 28 bits: tables of 4 GB and more are refused here rather than wrapped there.
+    const unsigned long long lim = 1ull << 32;
+    if ((unsigned long long)c->bvh.nTris * sizeof(Tri48) >= lim || (unsigned long long)c->bvh.nTris * sizeof(TriShade) >= lim ||
+        (unsigned long long)c->bvh.nNodes * sizeof(Node128) >= lim || (unsigned long long)c->bvh.nTris >= (1ull << 28)) {
+      lbvh_free(&c->bvh);
+      return fail(c, MOPTIX_ERR_LIMIT, "acceleration structure too large: triangle / node tables must stay below 4 GB (2^28 triangles at most)");
+    }
   }
+  if ((unsigned long long)c->mats.size() * sizeof(DevMaterial) >= (1ull << 32)) return fail(c, MOPTIX_ERR_LIMIT, "material table must stay below 4 GB");
   HIPCHK(c, hipStreamSynchronize(c->stream), "sync after upload");
   c->formatDecided = false;            // choose_node_format at the next render: it needs the camera
   c->sceneDirty = false; c->accelBuilt = true;
@@ -824,7 +877,11 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   if (!strcmp(name, "exit_threshold")) { if (value < 0 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "exit_threshold in [0,64]"); c->optExitThreshold = value; }
   else if (!strcmp(name, "leaf_size")) { if (value < 1 || value > kMaxLeaf) return fail(c, MOPTIX_ERR_INVALID, "leaf_size in [1,8]"); if (value != c->optLeafSize) c->accelBuilt = false; c->optLeafSize = value; }
   else if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 8) return fail(c, MOPTIX_ERR_INVALID, "blocks_per_cu in [1,8]"); c->optBlocksPerCU = value; }
-  else if (!strcmp(name, "kernel_variant")) { if (value != 0 && value != 3 && value != 4) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {0,3,4} (1 and 2 were removed in round 3)"); c->optVariant = value; c->variantExplicit = true; }
+  else if (!strcmp(name, "kernel_variant")) {
+    if (value != -1 && value != 0 && value != 3 && value != 4) return fail(c, MOPTIX_ERR_INVALID, "kernel_variant in {-1,0,3,4} (1 and 2 were removed in round 3)");
+    // -1: back to the library's own choice per launch (do_render: the packet kernel for long launches of eligible scenes)
+    c->optVariant = value < 0 ? 3 : value; c->variantExplicit = value >= 0;
+  }
   else if (!strcmp(name, "sample_buffer_mb")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "sample_buffer_mb >= 1"); c->optSampleBufMB = value; }
   else if (!strcmp(name, "leaf_threshold")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "leaf_threshold in [1,64]"); c->optLeafThreshold = value; }
   else if (!strcmp(name, "swap_lanes")) { if (value < 1 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "swap_lanes in [1,64]"); c->optSwapLanes = value; }
@@ -836,9 +893,10 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "slots_in_use")) { if (value < -1 || value > 1024) return fail(c, MOPTIX_ERR_INVALID, "slots_in_use in [-1,1024]"); c->optSlotsInUse = value; }
   else if (!strcmp(name, "builder")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "builder in {0,1}"); if (value != c->optBuilder) c->accelBuilt = false; c->optBuilder = value; }
   else if (!strcmp(name, "fast_shading")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "fast_shading in {0,1}"); c->optFastShading = value; }
-  else if (!strcmp(name, "node_format")) { if (value != 0 && value != 64 && value != 128) return fail(c, MOPTIX_ERR_INVALID, "node_format in {0,64,128}"); if (value != c->optNodeFormat) c->formatDecided = false; c->optNodeFormat = value; }
+  else if (!strcmp(name, "node_format")) { if (value != 0 && value != 64 && value != 128) return fail(c, MOPTIX_ERR_INVALID, "node_format in {0,64,128}"); c->formatDecided = false; c->optNodeFormat = value; }
   else if (!strcmp(name, "shadow_rule")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "shadow_rule in {0,1}"); c->optShadowRule = value; }
   else if (!strcmp(name, "watchdog_ms")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "watchdog_ms >= 1"); c->optWatchdogMs = value; }
+  else if (!strcmp(name, "comm_timeout_ms")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "comm_timeout_ms >= 1"); c->optCommTimeoutMs = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
 }
@@ -848,13 +906,14 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   if (!strcmp(name, "exit_threshold")) *value = c->optExitThreshold;
   else if (!strcmp(name, "leaf_size")) *value = c->optLeafSize;
   else if (!strcmp(name, "blocks_per_cu")) *value = c->optBlocksPerCU;
-  else if (!strcmp(name, "kernel_variant")) *value = c->optVariant;
+  else if (!strcmp(name, "kernel_variant")) *value = c->variantExplicit ? c->optVariant : -1;
   else if (!strcmp(name, "sample_buffer_mb")) *value = c->optSampleBufMB;
   else if (!strcmp(name, "leaf_threshold")) *value = c->optLeafThreshold;
   else if (!strcmp(name, "swap_lanes")) *value = c->optSwapLanes;
   else if (!strcmp(name, "starve_lanes")) *value = c->optStarveLanes;
   else if (!strcmp(name, "tile_major")) *value = c->optTileMajor;
   else if (!strcmp(name, "watchdog_ms")) *value = c->optWatchdogMs;
+  else if (!strcmp(name, "comm_timeout_ms")) *value = c->optCommTimeoutMs;
   else if (!strcmp(name, "node_format")) *value = c->optNodeFormat;
   else if (!strcmp(name, "node_format_used")) *value = c->nodeFormatUsed;
   else if (!strcmp(name, "fast_shading")) *value = c->optFastShading;
@@ -1092,8 +1151,7 @@ int moptix_gather_tiles(moptix_context c, int32_t dstRank) {
     }
     HIPCHK(c, hipGetLastError(), "unpack tiles");
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream), "sync after gather");
-  return MOPTIX_OK;
+  return comm_wait(c, "moptix_gather_tiles");
 }
 
 int moptix_reduce_frame(moptix_context c, int32_t dstRank) {
@@ -1106,8 +1164,7 @@ int moptix_reduce_frame(moptix_context c, int32_t dstRank) {
   if ((rc = ensure_accum(c)) != MOPTIX_OK) return rc;
   if (c->commRanks > 1)
     NCCLCHK(c, rccl().Reduce(accum_ptr(c), accum_ptr(c), 3 * c->accumPixels, ncclFloat, ncclSum, dstRank, c->comm, c->stream), "ncclReduce");
-  HIPCHK(c, hipStreamSynchronize(c->stream), "sync after reduce");
-  return MOPTIX_OK;
+  return c->commRanks > 1 ? comm_wait(c, "moptix_reduce_frame") : moptix_sync(c);
 }
 
 }  // extern "C"

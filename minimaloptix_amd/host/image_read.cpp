@@ -1,7 +1,7 @@
 // image_read.cpp -- decoder behind readImage(): what QImage(path) + pixelColor() give the reference's
 // texture upload (MinimalOptiX.cpp:446-466).  The image has no zlib/libpng headers, so inflate
-// (RFC 1951) and the PNG container (filters, bit depths, palette; non-interlaced) are implemented
-// here; binary PNM (P5/P6) is read as well, baseline JPEG in jpeg_read.cpp.
+// (RFC 1951) and the PNG container (filters, bit depths, palette; plain and Adam7-interlaced) are
+// implemented here; binary PNM (P5/P6) is read as well, baseline and progressive JPEG in jpeg_read.cpp.
 #include "image_io.h"
 
 #include <cstdio>
@@ -153,7 +153,7 @@ bool decodePNG(const std::vector<uint8_t>& file, int& width, int& height, std::v
     pos += 12 + (size_t)len;
   }
   if (w == 0 || h == 0 || w > 32768 || h > 32768) { err = "bad PNG header"; return false; }
-  if (interlace) { err = "interlaced PNG is not supported"; return false; }
+  if (interlace > 1) { err = "bad PNG interlace method"; return false; }
   int channels;
   switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break;
                    case 4: channels = 2; break; case 6: channels = 4; break; default: err = "bad PNG colour type"; return false; }
@@ -161,43 +161,62 @@ bool decodePNG(const std::vector<uint8_t>& file, int& width, int& height, std::v
     err = "bad PNG bit depth"; return false;
   }
   if (idat.size() < 2 || (idat[0] & 0x0f) != 8 || (idat[1] & 0x20)) { err = "bad zlib stream in PNG"; return false; }
+  // The image as one pass (interlace method 0) or as the seven passes of Adam7 (method 1; PNG specification, section 8.2): pass p
+  // holds the pixels (xs + i dx, ys + j dy) as an image of its own -- own scanlines, own filter bytes, filtering restarts with
+  // a zero row -- and a pass without pixels has no bytes at all.
+  struct Pass { uint32_t xs, ys, dx, dy; };
+  static const Pass adam7[7] = { { 0, 0, 8, 8 }, { 4, 0, 8, 8 }, { 0, 4, 4, 8 }, { 2, 0, 4, 4 }, { 0, 2, 2, 4 }, { 1, 0, 2, 2 }, { 0, 1, 1, 2 } };
+  static const Pass whole = { 0, 0, 1, 1 };
+  const int nPass = interlace ? 7 : 1;
+  size_t need = 0;
+  for (int pi = 0; pi < nPass; pi++) {
+    const Pass& ps = interlace ? adam7[pi] : whole;
+    const uint32_t pw = w > ps.xs ? (w - ps.xs + ps.dx - 1) / ps.dx : 0, ph = h > ps.ys ? (h - ps.ys + ps.dy - 1) / ps.dy : 0;
+    if (pw && ph) need += (((size_t)pw * channels * depth + 7) / 8 + 1) * ph;
+  }
   std::vector<uint8_t> raw;
-  const size_t stride = ((size_t)w * channels * depth + 7) / 8;
-  raw.reserve((stride + 1) * h);
-  if (!inflateRaw(idat.data() + 2, idat.size() - 2, raw) || raw.size() < (stride + 1) * h) { err = "cannot inflate PNG data"; return false; }
+  raw.reserve(need);
+  if (!inflateRaw(idat.data() + 2, idat.size() - 2, raw) || raw.size() < need) { err = "cannot inflate PNG data"; return false; }
   const int bpp = (channels * depth + 7) / 8;                            // filter unit
-  std::vector<uint8_t> prev(stride, 0), cur(stride);
   rgb.assign((size_t)w * h * 3, 0);
-  for (uint32_t y = 0; y < h; y++) {
-    const uint8_t* row = &raw[(stride + 1) * y];
-    const int ft = row[0];
-    for (size_t i = 0; i < stride; i++) {
-      const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
-      int v = row[1 + i];
-      switch (ft) { case 0: break; case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) >> 1; break;
-                    case 4: v += paeth(a, b, c); break; default: err = "bad PNG filter"; return false; }
-      cur[i] = (uint8_t)v;
-    }
-    uint8_t* o = &rgb[(size_t)y * w * 3];
-    for (uint32_t x = 0; x < w; x++) {
-      // sample k of pixel x as an 8-bit value (16-bit samples keep their high byte, as png_set_strip_16 does)
-      auto sample = [&](int k) -> int {
-        if (depth == 8) return cur[(size_t)x * channels + k];
-        if (depth == 16) return cur[((size_t)x * channels + k) * 2];
-        const size_t bitpos = (size_t)x * depth;
-        const int v = (cur[bitpos >> 3] >> (8 - depth - (int)(bitpos & 7))) & ((1 << depth) - 1);
-        return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
-      };
-      if (ctype == 3) {
-        const size_t idx = (size_t)sample(0);
-        if (3 * idx + 2 < plte.size()) { o[3 * x] = plte[3 * idx]; o[3 * x + 1] = plte[3 * idx + 1]; o[3 * x + 2] = plte[3 * idx + 2]; }
-      } else if (channels <= 2) {
-        o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = (uint8_t)sample(0);
-      } else {
-        o[3 * x] = (uint8_t)sample(0); o[3 * x + 1] = (uint8_t)sample(1); o[3 * x + 2] = (uint8_t)sample(2);
+  size_t at = 0;
+  for (int pi = 0; pi < nPass; pi++) {
+    const Pass& ps = interlace ? adam7[pi] : whole;
+    const uint32_t pw = w > ps.xs ? (w - ps.xs + ps.dx - 1) / ps.dx : 0, ph = h > ps.ys ? (h - ps.ys + ps.dy - 1) / ps.dy : 0;
+    if (!pw || !ph) continue;
+    const size_t stride = ((size_t)pw * channels * depth + 7) / 8;
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    for (uint32_t y = 0; y < ph; y++) {
+      const uint8_t* row = &raw[at]; at += stride + 1;
+      const int ft = row[0];
+      for (size_t i = 0; i < stride; i++) {
+        const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+        int v = row[1 + i];
+        switch (ft) { case 0: break; case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) >> 1; break;
+                      case 4: v += paeth(a, b, c); break; default: err = "bad PNG filter"; return false; }
+        cur[i] = (uint8_t)v;
       }
+      for (uint32_t x = 0; x < pw; x++) {
+        uint8_t* o = &rgb[((size_t)(ps.ys + y * ps.dy) * w + (ps.xs + x * ps.dx)) * 3];
+        // sample k of pixel x as an 8-bit value (16-bit samples keep their high byte, as png_set_strip_16 does)
+        auto sample = [&](int k) -> int {
+          if (depth == 8) return cur[(size_t)x * channels + k];
+          if (depth == 16) return cur[((size_t)x * channels + k) * 2];
+          const size_t bitpos = (size_t)x * depth;
+          const int v = (cur[bitpos >> 3] >> (8 - depth - (int)(bitpos & 7))) & ((1 << depth) - 1);
+          return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
+        };
+        if (ctype == 3) {
+          const size_t idx = (size_t)sample(0);
+          if (3 * idx + 2 < plte.size()) { o[0] = plte[3 * idx]; o[1] = plte[3 * idx + 1]; o[2] = plte[3 * idx + 2]; }
+        } else if (channels <= 2) {
+          o[0] = o[1] = o[2] = (uint8_t)sample(0);
+        } else {
+          o[0] = (uint8_t)sample(0); o[1] = (uint8_t)sample(1); o[2] = (uint8_t)sample(2);
+        }
+      }
+      prev.swap(cur);
     }
-    prev.swap(cur);
   }
   width = (int)w; height = (int)h;
   return true;
@@ -246,7 +265,7 @@ bool readImage(const std::string& path, int& width, int& height, std::vector<uin
   if (file.size() > 8 && !memcmp(file.data(), sig, 8)) ok = decodePNG(file, width, height, rgbTopDown, err);
   else if (file.size() > 2 && file[0] == 'P' && (file[1] == '5' || file[1] == '6')) ok = decodePNM(file, width, height, rgbTopDown, err);
   else if (file.size() > 3 && file[0] == 0xff && file[1] == 0xd8 && file[2] == 0xff) ok = decodeJPEG(file, width, height, rgbTopDown, err);
-  else { err = "unsupported image format (PNG, baseline JPEG and binary PNM are read)"; ok = false; }
+  else { err = "unsupported image format (PNG, JPEG and binary PNM are read)"; ok = false; }
   if (!ok) err = path + ": " + err;
   return ok;
 }

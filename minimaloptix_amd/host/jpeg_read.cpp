@@ -1,8 +1,11 @@
-// jpeg_read.cpp -- baseline (sequential, Huffman, 8-bit) JPEG decoder behind readImage(): QImage reads albedoTex
+// jpeg_read.cpp -- JPEG decoder (8-bit, Huffman; sequential and progressive) behind readImage(): QImage reads albedoTex
 // files through libjpeg, so this follows libjpeg's decoder arithmetic -- the "islow" integer IDCT, triangle
 // ("fancy") chroma upsampling and the fixed-point YCbCr->RGB tables -- and reproduces its pixels exactly
-// (tests compare with libjpeg-turbo through PIL).  Progressive, arithmetic-coded, 12-bit and CMYK files are
-// reported as unsupported.
+// (tests compare with libjpeg-turbo through PIL).  A progressive file (SOF2; ITU-T T.81 Annex G) is a sequence of scans
+// that each deliver a band of coefficients (spectral selection Ss..Se) at some precision (successive approximation
+// Ah / Al): the coefficients of every block are kept until the last scan and transformed once, which is what libjpeg
+// does with a complete file (its block smoothing only applies while refinement scans are still missing).
+// Arithmetic-coded, 12-bit and CMYK files are reported as unsupported.
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -27,7 +30,8 @@ struct HuffTable {
   }
 };
 
-struct Component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int wBlocks = 0, hBlocks = 0, dw = 0, dh = 0; int pred = 0; std::vector<uint8_t> px; int stride = 0; };
+struct Component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int wBlocks = 0, hBlocks = 0, dw = 0, dh = 0; int pred = 0; std::vector<uint8_t> px; int stride = 0;
+                   std::vector<int16_t> coefs; };      // progressive: 64 coefficients (natural order) per block, wBlocks x hBlocks
 
 struct BitSrc {
   const uint8_t* p; size_t n, pos; uint32_t buf = 0; int cnt = 0; bool hitMarker = false;
@@ -145,6 +149,75 @@ void upsampleH2V2Fancy(const uint8_t* a, const uint8_t* b, int n, uint8_t* out) 
   out[2 * n - 2] = (uint8_t)((thiscol * 3 + lastcol + 8) >> 4); out[2 * n - 1] = (uint8_t)((thiscol * 4 + 7) >> 4);
 }
 
+// ---- progressive scans (T.81 G.1.2): one call per block of the scan; eobrun = blocks of this band still to be skipped ----
+// first pass over the DC coefficient: the difference to the previous block's value, delivered with its low Al bits missing
+bool progDcFirst(BitSrc& bs, const HuffTable& t, int al, int& pred, int16_t* blk) {
+  const int s = decodeHuff(bs, t);
+  if (s < 0 || s > 11) return false;
+  pred += s ? extend(bs.bits(s), s) : 0;
+  blk[0] = (int16_t)(pred * (1 << al));
+  return true;
+}
+// a later pass over the DC coefficient: one more bit of it
+void progDcRefine(BitSrc& bs, int al, int16_t* blk) { if (bs.bit()) blk[0] = (int16_t)(blk[0] | (1 << al)); }
+// first pass over the band ss..se of the AC coefficients: run / size pairs as in a sequential scan, values scaled by 2^Al; a
+// size of zero with a run r < 15 announces 2^r + (r more bits) blocks whose band holds nothing more, this one included
+bool progAcFirst(BitSrc& bs, const HuffTable& t, int ss, int se, int al, int& eobrun, int16_t* blk) {
+  if (eobrun > 0) { eobrun--; return true; }
+  for (int k = ss; k <= se; k++) {
+    const int rs = decodeHuff(bs, t);
+    if (rs < 0) return false;
+    const int r = rs >> 4, sz = rs & 15;
+    if (sz) {
+      k += r;
+      if (k > se) return false;
+      blk[kZigzag[k]] = (int16_t)(extend(bs.bits(sz), sz) * (1 << al));
+    } else if (r == 15) {
+      k += 15;
+    } else {
+      eobrun = (1 << r) - 1;
+      if (r) eobrun += bs.bits(r);
+      break;
+    }
+  }
+  return true;
+}
+// a later pass over the band: every coefficient that is already non-zero gets one correction bit (its magnitude grows by 2^Al
+// when the bit is set and that bit of it is still clear), and new coefficients of magnitude 2^Al appear after runs of r
+// coefficients that STAY zero -- the correction bits of the non-zero ones passed on the way are interleaved with them
+bool progAcRefine(BitSrc& bs, const HuffTable& t, int ss, int se, int al, int& eobrun, int16_t* blk) {
+  const int plus = 1 << al, minus = -(1 << al);
+  auto correct = [&](int16_t& c) { if (bs.bit() && (c & plus) == 0) c = (int16_t)(c + (c >= 0 ? plus : minus)); };
+  int k = ss;
+  if (eobrun == 0) {
+    for (; k <= se; k++) {
+      const int rs = decodeHuff(bs, t);
+      if (rs < 0) return false;
+      int r = rs >> 4; const int sz = rs & 15;
+      int newVal = 0;
+      if (sz) {
+        if (sz != 1) return false;                       // a new coefficient of this pass has magnitude 2^Al, nothing else
+        newVal = bs.bit() ? plus : minus;
+      } else if (r != 15) {
+        eobrun = 1 << r;
+        if (r) eobrun += bs.bits(r);
+        break;                                           // the rest of this block's band: correction bits only (below)
+      }
+      for (; k <= se; k++) {
+        int16_t& c = blk[kZigzag[k]];
+        if (c != 0) correct(c);
+        else if (--r < 0) break;                         // the (r+1)-th zero: where the new coefficient goes (or, for ZRL, where the run of 16 ends)
+      }
+      if (newVal && k <= se) blk[kZigzag[k]] = (int16_t)newVal;
+    }
+  }
+  if (eobrun > 0) {
+    for (; k <= se; k++) { int16_t& c = blk[kZigzag[k]]; if (c != 0) correct(c); }
+    eobrun--;
+  }
+  return true;
+}
+
 }  // namespace
 
 bool decodeJPEG(const std::vector<uint8_t>& file, int& width, int& height, std::vector<uint8_t>& rgb, std::string& err) {
@@ -152,7 +225,7 @@ bool decodeJPEG(const std::vector<uint8_t>& file, int& width, int& height, std::
   HuffTable dcT[4], acT[4];
   std::vector<Component> comps;
   int W = 0, H = 0, hmax = 1, vmax = 1, restartInterval = 0;
-  bool haveFrame = false, adobe = false; int adobeTransform = -1;
+  bool haveFrame = false, adobe = false, progressive = false; int adobeTransform = -1;
   size_t pos = 2;
   auto fail = [&](const char* m) { err = m; return false; };
   while (pos + 4 <= file.size()) {
@@ -185,7 +258,8 @@ bool decodeJPEG(const std::vector<uint8_t>& file, int& width, int& height, std::
         memcpy(t.vals, d + i, total); i += total;
         t.build(); t.present = true;
       }
-    } else if (marker == 0xc0 || marker == 0xc1) {                              // SOF0 / SOF1 (8-bit sequential Huffman)
+    } else if (marker == 0xc0 || marker == 0xc1 || marker == 0xc2) {            // SOF0 / SOF1 (8-bit sequential Huffman), SOF2 (progressive)
+      progressive = marker == 0xc2;
       if (dl < 6 || d[0] != 8) return fail("only 8-bit JPEG is supported");
       H = be16(d + 1); W = be16(d + 3);
       const int nc = d[5];
@@ -201,9 +275,9 @@ bool decodeJPEG(const std::vector<uint8_t>& file, int& width, int& height, std::
         c.wBlocks = mcusX * c.h; c.hBlocks = mcusY * c.v;
         c.dw = (W * c.h + hmax - 1) / hmax; c.dh = (H * c.v + vmax - 1) / vmax;
         c.stride = c.wBlocks * 8; c.px.assign((size_t)c.stride * c.hBlocks * 8, 0);
+        if (progressive) c.coefs.assign((size_t)c.wBlocks * c.hBlocks * 64, 0);
       }
       haveFrame = true;
-    } else if (marker == 0xc2) { return fail("progressive JPEG is not supported");
     } else if (marker >= 0xc3 && marker <= 0xcf && marker != 0xc4 && marker != 0xc8 && marker != 0xcc) { return fail("unsupported JPEG coding process");
     } else if (marker == 0xdd) { if (dl >= 2) restartInterval = be16(d);
     } else if (marker == 0xee) { if (dl >= 12 && !memcmp(d, "Adobe", 5)) { adobe = true; adobeTransform = d[11]; }
@@ -217,9 +291,14 @@ bool decodeJPEG(const std::vector<uint8_t>& file, int& width, int& height, std::
         for (Component& c : comps) if (c.id == d[1 + 2 * i]) cp = &c;
         if (!cp) return fail("JPEG scan names an unknown component");
         cp->td = d[2 + 2 * i] >> 4; cp->ta = d[2 + 2 * i] & 15;
-        if (cp->td > 3 || cp->ta > 3 || !dcT[cp->td].present || !acT[cp->ta].present || !haveQ[cp->tq]) return fail("JPEG scan uses a missing table");
         sc.push_back(cp);
       }
+      const int ss = d[1 + 2 * ns], se = d[2 + 2 * ns], ah = d[3 + 2 * ns] >> 4, al = d[3 + 2 * ns] & 15;
+      for (Component* cp : sc) {                         // a progressive scan needs only the tables of the band it carries
+        const bool needDc = !progressive || (ss == 0 && ah == 0), needAc = !progressive || ss > 0;
+        if (cp->td > 3 || cp->ta > 3 || (needDc && !dcT[cp->td].present) || (needAc && !acT[cp->ta].present) || !haveQ[cp->tq]) return fail("JPEG scan uses a missing table");
+      }
+      if (progressive && (ss > se || se > 63 || al > 13 || (ss == 0 && se != 0) || (ss > 0 && ns != 1))) return fail("bad progressive JPEG scan parameters");
       BitSrc bs{ file.data(), file.size(), pos + 2 + len };
       for (Component& c : comps) c.pred = 0;
       const bool interleaved = ns > 1;
@@ -229,18 +308,31 @@ bool decodeJPEG(const std::vector<uint8_t>& file, int& width, int& height, std::
       else { mcusX = (sc[0]->dw + 7) / 8; mcusY = (sc[0]->dh + 7) / 8; }        // a single-component scan covers only real blocks
       int toRestart = restartInterval;
       int16_t coef[64];
+      int eobrun = 0;
       for (int my = 0; my < mcusY; my++) for (int mx = 0; mx < mcusX; mx++) {
         if (restartInterval && toRestart == 0) {
           bs.reset();
           while (bs.pos + 1 < bs.n && !(bs.p[bs.pos] == 0xff && bs.p[bs.pos + 1] >= 0xd0 && bs.p[bs.pos + 1] <= 0xd7)) bs.pos++;
           bs.pos += 2;
           for (Component* c : sc) c->pred = 0;
+          eobrun = 0;
           toRestart = restartInterval;
         }
         toRestart--;
         for (Component* c : sc) {
           const int bh = interleaved ? c->h : 1, bv = interleaved ? c->v : 1;
           for (int by = 0; by < bv; by++) for (int bx = 0; bx < bh; bx++) {
+            if (progressive) {
+              const int blockX = mx * bh + bx, blockY = my * bv + by;
+              int16_t scratch[64];                      // a block outside the component's array (cannot happen for a well-formed scan) still consumes its bits
+              int16_t* blk = (blockX < c->wBlocks && blockY < c->hBlocks) ? &c->coefs[((size_t)blockY * c->wBlocks + blockX) * 64] : (memset(scratch, 0, sizeof(scratch)), scratch);
+              bool ok = true;
+              if (ss == 0) { if (ah == 0) ok = progDcFirst(bs, dcT[c->td], al, c->pred, blk); else progDcRefine(bs, al, blk); }
+              else if (ah == 0) ok = progAcFirst(bs, acT[c->ta], ss, se, al, eobrun, blk);
+              else ok = progAcRefine(bs, acT[c->ta], ss, se, al, eobrun, blk);
+              if (!ok) return fail("corrupt progressive JPEG data");
+              continue;
+            }
             memset(coef, 0, sizeof(coef));
             int s = decodeHuff(bs, dcT[c->td]);
             if (s < 0 || s > 11) return fail("corrupt JPEG data (DC)");
@@ -268,6 +360,12 @@ bool decodeJPEG(const std::vector<uint8_t>& file, int& width, int& height, std::
     pos += 2 + len;
   }
   if (!haveFrame) return fail("no JPEG frame");
+  if (progressive)                                     // every scan has been read: one inverse transform per block
+    for (Component& c : comps) {
+      if (!haveQ[c.tq]) return fail("JPEG component without a quantisation table");
+      for (int by = 0; by < c.hBlocks; by++) for (int bx = 0; bx < c.wBlocks; bx++)
+        idctIslow(&c.coefs[((size_t)by * c.wBlocks + bx) * 64], qt[c.tq], &c.px[(size_t)by * 8 * c.stride + (size_t)bx * 8], c.stride);
+    }
   width = W; height = H;
   rgb.assign((size_t)W * H * 3, 0);
   if (comps.size() == 1) {

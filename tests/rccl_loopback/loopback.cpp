@@ -1,4 +1,4 @@
-// rccl_loopback -- TEST INFRASTRUCTURE, not part of the product: the nine RCCL entry points libmoptix.so binds
+// rccl_loopback -- TEST INFRASTRUCTURE, not part of the product: the RCCL entry points libmoptix.so binds (nine + the two optional ones)
 // (csrc/moptix_api.hip RcclApi), implemented over POSIX shared memory + hipMemcpy, so that the N > 1 branches of
 // moptix_gather_tiles / moptix_reduce_frame (pack -> send; grouped receives -> unpack; reduce) run as N processes on a ONE-GPU box.
 // RCCL itself refuses a communicator whose ranks share a device ("Duplicate GPU detected", init.cc), and no multi-GPU box has been
@@ -8,6 +8,11 @@
 // Protocol: one shared segment per unique id, one mailbox per ordered (src, dst) pair: the sender waits for `full == 0`, copies a
 // chunk device -> mailbox, sets `full`; the receiver waits for `full`, copies mailbox -> device, clears it.  Every wait has a
 // deadline (ncclSystemError after 60 s): a missing peer fails the call instead of hanging the box.
+//
+// MOPTIX_LOOPBACK_STUCK=1 models what RCCL does when a peer never joins a collective: ncclRecv returns at once after putting a
+// kernel on the caller's stream that spins until the communicator is aborted (ncclCommAbort raises a flag in host-mapped memory;
+// the kernel also gives up by itself after 30 s so that no test can hang the GPU).  libmoptix.so's deadline (comm_wait: poll the
+// stream, ncclCommGetAsyncError, ncclCommAbort) is tested against it (tests/test_gpu_rccl_loopback.py).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -28,7 +33,12 @@ constexpr int kMaxRanks = 8;
 constexpr size_t kChunk = 1 << 20;      // bytes per mailbox
 struct Mailbox { std::atomic<uint32_t> full; uint32_t bytes; char pad[56]; char data[kChunk]; };
 struct Segment { std::atomic<uint32_t> arrived; char pad[60]; Mailbox box[kMaxRanks][kMaxRanks]; };
-struct Comm { int rank, n; Segment* seg; char name[64]; };
+struct Comm { int rank, n; Segment* seg; char name[64]; uint32_t* abortHost; uint32_t* abortDev; };
+
+__global__ void k_stuck(const uint32_t* abortFlag, unsigned long long maxTicks) {      // a collective's kernel whose peer never arrives
+  const unsigned long long t0 = wall_clock64();                                         // 100 MHz
+  while (__hip_atomic_load(abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u && wall_clock64() - t0 < maxTicks) __builtin_amdgcn_s_sleep(127);
+}
 
 bool wait_for(std::atomic<uint32_t>& flag, uint32_t want) {
   const auto t0 = std::chrono::steady_clock::now();
@@ -90,6 +100,11 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   if (p == MAP_FAILED) return ncclSystemError;
   Comm* c = new Comm; c->rank = rank; c->n = nranks; c->seg = (Segment*)p;
   strncpy(c->name, id.internal, sizeof(c->name) - 1); c->name[sizeof(c->name) - 1] = 0;
+  c->abortHost = nullptr; c->abortDev = nullptr;
+  if (hipHostMalloc((void**)&c->abortHost, 64, hipHostMallocMapped) == hipSuccess) {
+    *c->abortHost = 0;
+    if (hipHostGetDevicePointer((void**)&c->abortDev, c->abortHost, 0) != hipSuccess) c->abortDev = nullptr;
+  }
   c->seg->arrived.fetch_add(1);
   const auto t0 = std::chrono::steady_clock::now();      // like ncclCommInitRank: returns once every rank has arrived
   while ((int)c->seg->arrived.load() < nranks) {
@@ -104,7 +119,18 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   Comm* c = (Comm*)comm;
   if (!c) return ncclInvalidArgument;
   munmap(c->seg, sizeof(Segment));
-  delete c;
+  delete c;                                  // (the 64 bytes of the abort flag stay mapped: a kernel may still be reading them)
+  return ncclSuccess;
+}
+ncclResult_t ncclCommAbort(ncclComm_t comm) {
+  Comm* c = (Comm*)comm;
+  if (!c) return ncclInvalidArgument;
+  if (c->abortHost) __atomic_store_n(c->abortHost, 1u, __ATOMIC_RELEASE);      // kernels of this communicator leave
+  return ncclCommDestroy(comm);
+}
+ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError) {
+  if (!comm || !asyncError) return ncclInvalidArgument;
+  *asyncError = ncclSuccess;
   return ncclSuccess;
 }
 const char* ncclGetErrorString(ncclResult_t r) {
@@ -126,6 +152,11 @@ ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t type, i
 ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream) {
   Comm* c = (Comm*)comm;
   if (!c || !type_bytes(type) || peer < 0 || peer >= c->n || peer == c->rank) return ncclInvalidArgument;
+  if (getenv("MOPTIX_LOOPBACK_STUCK")) {      // the peer never sends: what the caller gets from RCCL then is a kernel that does not end
+    if (!c->abortDev) return ncclSystemError;
+    k_stuck<<<1, 64, 0, stream>>>(c->abortDev, 3000000000ull);
+    return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+  }
   return recv_bytes(c, recvbuff, nullptr, count * type_bytes(type), peer, stream);
 }
 ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t type, ncclRedOp_t op, int root, ncclComm_t comm, hipStream_t stream) {

@@ -64,8 +64,10 @@ def test_trace_kernel_resources_are_pinned():
     assert len(bench) == 1, sorted(res)[:5]
     r = bench[0]
     assert r["vgpr_count"] <= 168, r                       # three workgroups of four waves per CU
-    assert r["vgpr_spill_count"] <= 8, r                   # 5 today
-    assert r["sgpr_spill_count"] <= 60, r                  # 49 today (round 3: 111)
+    # pinned at today's numbers (round 5: 2 vector, 57 scalar; round 3: 11 / 111): an edit that moves them has to say so here and in
+    # profiles/r05_kernel_resources.txt, where the numbers are kept per round
+    assert r["vgpr_spill_count"] <= 2, r
+    assert r["sgpr_spill_count"] <= 57, r
     # LDS: three workgroups per CU.  The CU hands LDS out in blocks of 1,280 bytes: 42 blocks = 53,760 bytes each (54,128 bytes ran two
     # workgroups per CU in round 4 -- frame 105 instead of 79 ms -- although hipOccupancyMaxActiveBlocksPerMultiprocessor says 3 up to 54,592)
     assert r["group_segment_fixed_size"] <= 53760, r

@@ -323,7 +323,7 @@ def test_packet_variant_on_the_glass_and_million_triangle_scenes(gpu_ctx):
                 gpu_ctx.load(hs)
                 out[v] = _render(gpu_ctx, seeds, counted=True)
         finally:
-            gpu_ctx.set_option("kernel_variant", 3)
+            gpu_ctx.set_option("kernel_variant", -1)
         assert np.array_equal(out[3][0], out[4][0]), kind
         for f in ("primaryRays", "bounceRays", "shadowRays", "closestHits", "lightLoads", "samples"):
             assert getattr(out[3][1], f) == getattr(out[4][1], f), (kind, f)
@@ -353,7 +353,7 @@ def test_borrowed_slots_for_deep_paths_shadow_rays_change_nothing(gpu_ctx):
                     for f in ("primaryRays", "bounceRays", "shadowRays", "closestHits", "lightLoads", "samples"):
                         assert getattr(rst, f) == getattr(st, f), (kind, aux_depth, slots, f)
         finally:
-            gpu_ctx.set_option("kernel_variant", 3)
+            gpu_ctx.set_option("kernel_variant", -1)
             gpu_ctx.set_option("aux_depth", 16)
             gpu_ctx.set_option("slots_in_use", -1)
 
@@ -515,7 +515,7 @@ def test_round4_options_and_guards(gpu_ctx):
         span, tail = gpu_ctx.get_option("counted_span_us"), gpu_ctx.get_option("counted_tail_us")
         assert st.rays > 0 and span > 0 and 0 <= tail <= span, (span, tail)
     finally:
-        gpu_ctx.set_option("kernel_variant", 3)
+        gpu_ctx.set_option("kernel_variant", -1)
     import ctypes
     p = type(hs.params)()
     ctypes.memmove(ctypes.byref(p), ctypes.byref(hs.params), ctypes.sizeof(p))

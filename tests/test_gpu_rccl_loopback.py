@@ -36,6 +36,18 @@ def test_n_ranks_gather_and_reduce_through_the_c_abi(n):
     assert "bit-identical to the one-rank frame" in p.stdout and ("over %d ranks" % n) in p.stdout, p.stdout[-1000:]
 
 
+@pytest.mark.gpu
+def test_a_peer_that_never_sends_ends_the_collective_at_its_deadline():
+    """moptix_gather_tiles with a peer that joined the communicator and then never calls: the receive's kernel sits on rank 0's
+    stream and does not end (MOPTIX_LOOPBACK_STUCK models RCCL's spinning kernel).  comm_wait polls the stream, aborts the
+    communicator after comm_timeout_ms (1.5 s here) and the call returns MOPTIX_ERR_COMM; the context is a one-rank context again."""
+    e = _env(); e["MOPTIX_LOOPBACK_STUCK"] = "1"; e["RCCL_TWO_RANKS_DEAD_PEER"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "rccl_two_ranks.py"), "2", "--same-device"],
+                       env=e, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    assert "came back after" in p.stdout and "code -6" in p.stdout and "dead peer: rank 0's collective was aborted" in p.stdout, p.stdout[-1500:]
+
+
 def _read_png(path):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from test_gpu_configs import _read_png as rp

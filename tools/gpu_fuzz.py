@@ -52,15 +52,28 @@ for case in range(cases):
     if not ok:
         # Is it the scheduler or the tree?  The reference's float triangle test (pt_geom.h tri_test = Geometry.cu:121-160) can accept a
         # grazing hit on a needle triangle at a point OUTSIDE that triangle's bounding box; whether a traversal ever tests the triangle
-        # then depends on the boxes around it ("the one exception to rule D5").  Same scheduler options on the
-        # reference's tree: equal bits = the tree was the cause.
-        for k, v in dict(leaf_size=4, builder=0, node_format=128).items():
-            ctx.set_option(k, v)
+        # then depends on the boxes around it ("the one exception to rule D5").  The proof is made on the
+        # CANDIDATE's own tree: the per-lane kernel (variant 0: no scheduler, no 64-byte decode, the branched stack tail) with the
+        # candidate's leaf_size and builder must give the candidate's bits -- then scheduler, Node64 decode and builder agree with
+        # the simplest kernel on that tree and only the tree's shape separates it from the reference.  Anything else is a MISMATCH.
+        ctx.set_option("kernel_variant", 0)
         ctx.load(hs); ctx.accum_clear(); ctx.render(seeds)
-        verdict = "TREE-DEPENDENT HIT (%d pixels)" % int((ctx.accum_read() != got).any(axis=-1).sum()) if np.array_equal(ctx.accum_read(), ref) else "MISMATCH"
-        tree_cases += verdict != "MISMATCH"; ok = verdict != "MISMATCH"
+        own = ctx.accum_read()
+        if np.array_equal(own, got):
+            verdict = "TREE-DEPENDENT HIT (%d pixels; variant 0 on the candidate's tree gives the candidate's bits)" % int((ref != got).any(axis=-1).sum())
+        elif used == (4, 64):
+            # the per-lane kernel walks the 128-byte boxes of the same tree; the candidate walked their quantised (larger) form
+            ctx.set_option("kernel_variant", 4); ctx.set_option("node_format", 128)
+            ctx.load(hs); ctx.accum_clear(); ctx.render(seeds)
+            verdict = "MISMATCH (the 64-byte nodes differ from the 128-byte nodes of the same tree: decode bug, or a grazing hit the larger boxes admit -- replay with ONLY=%d and tools/gpu_fuzz_pixel.py)" % case \
+                if np.array_equal(ctx.accum_read(), own) else "MISMATCH"
+        else:
+            verdict = "MISMATCH"
+        tree_cases += verdict.startswith("TREE"); ok = verdict.startswith("TREE")
     print("case %3d %-18s %s %dx%d spp %d seed0 %d rank %d/%d rule %d %s ran %s -> %s" % (case, scene, kw, w, h, spp, seed0, rank, ranks, rule, opts, used,
                                                                                         verdict), flush=True)
     bad += 0 if ok else 1
-print("mismatches:", bad, " tree-dependent grazing hits:", tree_cases)
-sys.exit(1 if bad else 0)
+# a ceiling on the excuse: round 4 found 1 tree-dependent pixel-sample in 3,600 cases
+ceiling = max(1, cases // 400)
+print("mismatches:", bad, " tree-dependent grazing hits:", tree_cases, "(ceiling %d)" % ceiling)
+sys.exit(1 if bad or tree_cases > ceiling else 0)

@@ -20,26 +20,30 @@ import bench   # noqa: E402
 
 src = sys.argv[1]
 dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "profiles", "traffic.json")
+bench_args = sys.argv[3].split() if len(sys.argv) > 3 else []      # the bench.py arguments the passes were made with (tools/r05_configs.sh): stamps the workload
 agg, cnt = collections.defaultdict(float), collections.Counter()
 kernels = set()
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r.get("Kernel_Name", "")
-        if not re.search(r"pt_(queue|packet)kernel<false, true(, false(, (false|true)(, (false|true))?)?)?>", name):      # the exact-mode trace kernel only
+        if not re.search(r"pt_(queue|packet)kernel(_lean)?<false, true(, false(, (false|true)(, (false|true))?)?)?>", name):      # the exact-mode trace kernel only
             continue
-        kernels.add(re.search(r"pt_\w+kernel<[^>]*>", name).group(0).replace(" ", ""))
+        kernels.add(re.search(r"pt_\w+kernel\w*<[^>]*>", name).group(0).replace(" ", ""))
         k = r.get("Counter_Name")
         agg[k] += float(r.get("Counter_Value", 0)); cnt[k] += 1
 per = {k: agg[k] / cnt[k] for k in agg}
 need = ("FETCH_SIZE", "WRITE_SIZE")
 if any(k not in per for k in need):
-    raise SystemExit("missing counters: have %s" % sorted(per))
+    print("missing counters (fabric fields will be null): have %s" % sorted(per))
+    for k in need:
+        per.setdefault(k, float("nan"))
 out = {
     "source": "%s (separate --pmc passes of `python3 bench.py --steps 1 --warmup 0`)" % src,
     "source_hash": bench.source_hash(REPO),
+    "workload": bench.workload_text(bench.parse_args(bench_args)),
     "kernel": ", ".join(sorted(kernels)),
     "FETCH_SIZE_KB_per_launch": per["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": per["WRITE_SIZE"],
-    "traffic_GB_per_launch": round((per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024 / 1e9, 1),
+    "traffic_GB_per_launch": round((per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024 / 1e9, 1) if per["FETCH_SIZE"] == per["FETCH_SIZE"] and per["WRITE_SIZE"] == per["WRITE_SIZE"] else None,
     "TCC_HIT_per_launch": per.get("TCC_HIT_sum"), "TCC_MISS_per_launch": per.get("TCC_MISS_sum"),
     "tcc_hit_rate": round(per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in per else None,
     "SQ": {k: per[k] for k in sorted(per) if k.startswith("SQ_")},

@@ -38,6 +38,25 @@ def rank_main(rank, n, same, idfile, outdir):
             time.sleep(0.01)
         uid = open(idfile, "rb").read()
     ctx.comm_init(uid, rank, n)
+    if os.environ.get("RCCL_TWO_RANKS_DEAD_PEER"):
+        # a peer that joins the communicator and then never calls the collective: rank 0's gather must come back with
+        # MOPTIX_ERR_COMM after "comm_timeout_ms" (csrc/moptix_api.hip comm_wait), not block for good
+        if rank != 0:
+            time.sleep(4.0)
+            return
+        ctx.set_option("comm_timeout_ms", 1500)
+        ctx.set_partition(rank, n); ctx.load(hs); ctx.accum_clear(); ctx.render(seeds)
+        t0 = time.perf_counter()
+        try:
+            ctx.gather_tiles(0)
+        except M.MoptixError as e:
+            dt = time.perf_counter() - t0
+            ok = e.code == M.ERR_COMM and ctx.get_option("comm_ranks") == 0
+            print("rank 0: moptix_gather_tiles came back after %.2f s with code %d (%s); communicator size now %d" % (dt, e.code, e, ctx.get_option("comm_ranks")), flush=True)
+            ctx.set_partition(0, 1); ctx.accum_clear(); ctx.render(seeds[:1])      # the context still renders as a one-rank context
+            ctx.close()
+            raise SystemExit(0 if ok and dt < 30.0 else 1)
+        raise SystemExit("rank 0: moptix_gather_tiles returned without an error although rank 1 never sent")
     # tile split + gather
     ctx.set_partition(rank, n)
     ctx.load(hs)
@@ -93,6 +112,9 @@ def main():
         if any(rc != 0 for rc in rcs):
             print("FAIL: rank exit codes %s" % rcs)
             return 1
+        if os.environ.get("RCCL_TWO_RANKS_DEAD_PEER"):
+            print("dead peer: rank 0's collective was aborted at its deadline, every rank exited")
+            return 0
         # the one-rank frame, in this process
         import minimaloptix_amd as M
         ctx = M.Context(0)
