@@ -32,6 +32,7 @@ NODE_BYTES = 64             # the node record the packet kernel fetches on coffe
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
 GATHER_CEILING_FILE = os.path.join("profiles", "r03_gather_ceiling.txt")    # output of tools/micro/gather on MI355X
 VALU_CEILING_FILE = os.path.join("profiles", "r04_valu_ceiling.txt")        # output of tools/micro/valu_issue on MI355X
+PIPELINE_FROM_RANKS = 8     # two frames in flight by default from this many ranks on (GpuFrame)
 KERNEL_WAVES_PER_SIMD = 3   # what the trace kernel's 168 registers and 53 KB of LDS allow (csrc/packetkernel.hip)
 
 
@@ -324,11 +325,15 @@ class GpuFrame:
         self.seeds = M.launch_seeds(a.spp)
         if self.sample_split:
             self.seeds = D.sample_split_seeds(self.seeds, self.part_rank, self.part_n)      # launches i = rank mod N
-        # Frame pipelining (N > 1, opt-in MOPTIX_BENCH_PIPELINE=1): a rank's launch is short (frame / N) and its last
-        # milliseconds are a drain in which a few deep paths finish while most of the GPU idles.  Two contexts render
-        # alternate frames on their own streams; every frame is still completed and gathered inside the timed region.
-        # Measured +8 % on an emulated 8-way share of one GPU, never run beside RCCL kernels on a real multi-GPU node.
-        self.pipeline = os.environ.get("MOPTIX_BENCH_PIPELINE", "0") == "1"
+        # Two frames in flight (default from PIPELINE_FROM_RANKS ranks on; MOPTIX_BENCH_PIPELINE=1 / 0 forces it on / off): a rank's
+        # launch is short (frame / N) and its last ~13 ms are a drain in which a few depth-capped paths finish while most of the GPU
+        # idles.  Two contexts render alternate frames on their own streams (and gather them on their own communicators, oldest frame
+        # first on every rank); every frame is still completed and gathered inside the timed region.  Measured on the shares of ONE
+        # GPU (profiles/r05_scaling_emulation.txt): an 8-way share 43.4 -> 39.7 ms (89 % -> 98 % of ideal), a 4-way share
+        # 77.1 -> 76.2 ms, the whole frame 310 -> 323 ms (worse: hence not below 8 ranks).  Never run beside RCCL's kernels on a real
+        # multi-GPU node; the collectives have a deadline (csrc/moptix_api.hip comm_wait).
+        pl = os.environ.get("MOPTIX_BENCH_PIPELINE", "")
+        self.pipeline = pl == "1" or (pl == "" and self.part_n >= PIPELINE_FROM_RANKS)
         self.ctxs, self.accums = [self.ctx], [self.accum]
         if self.pipeline:
             ctx2 = M.Context(local)

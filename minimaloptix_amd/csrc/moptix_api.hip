@@ -185,8 +185,8 @@ void fill_view(moptix_context c, SceneView& v) {
 // each, tests 17 % more triangles (it lost 6 % in round 3 and is level since round 4).  Static measures of the tree (surface-area inflation: 0.3 % for the dining
 // room, 0.7 % for coffee) and synthetic rays miss this, so the scene is asked with its own paths: one sample per pixel of a
 // 128-pixel-wide grid over the camera's view, cut at depth 6, walked under both forms; the counts are priced with the per-step
-// costs fitted to coffee, the coffee pot, the glass knot and the dining room (round 4: a triangle test = 1.3 node steps of the
-// 128-byte form; a 64-byte step = 0.78 of one).  Decided at the first render after a build or a change of frame size; a
+// costs fitted to coffee, the coffee pot, the glass knot and the dining room (a triangle test = 1.3 node steps of the
+// 128-byte form; a 64-byte step = 0.93 of one since round 5, 0.78 in round 4).  Decided at the first render after a build or a change of frame size; a
 // later change of camera keeps the verdict (moptix_set_params).
 constexpr int kProbeWidth = 128;
 int choose_node_format(moptix_context c) {
@@ -213,10 +213,13 @@ int choose_node_format(moptix_context c) {
   if (dOvf) (void)hipFree(dOvf);
   if (e != hipSuccess) return hipFail(c, e, "node format probe");
   // Round 4 re-fit (profiles/r04_node_format.txt): the 64-byte step lost 45 instructions (sign-selected plane words) and the leaf pass
-  // its dependent fetches, so a triangle test weighs 1.3 node steps instead of 3.5 and a 64-byte step 0.78 of a 128-byte one; the
-  // 64-byte form now wins or ties on all four test scenes (the dining room, which it lost by 7 % in round 3, is level).
+  // its dependent fetches, so a triangle test weighs 1.3 node steps instead of 3.5 and a 64-byte step 0.78 of a 128-byte one.
   const double cost128 = (double)c->probeCounts[0] + 1.3 * (double)c->probeCounts[1];
-  const double cost64 = 0.78 * (double)c->probeCounts[2] + 1.3 * (double)c->probeCounts[3];
+  // Round 5 re-fit (profiles/r05_node_format.txt): the 128-byte step is fetched by the ray's signs now (pt_path.h: no min / max per plane
+  // pair), which makes it the cheaper step in instructions (100 against 130) and leaves the 64-byte one its four gathers against seven:
+  // a 64-byte step = 0.93 of a 128-byte one.  Coffee, coffee + pot and the glass knot keep the 64-byte nodes (2-3 % faster), the dining
+  // room -- whose quantised wall boxes cost it 17 % more triangle tests -- goes back to the 128-byte ones (38.7 against 40.6 ms).
+  const double cost64 = 0.93 * (double)c->probeCounts[2] + 1.3 * (double)c->probeCounts[3];
   c->nodeFormatUsed = cost64 < cost128 ? 64 : 128;
   if (getenv("MOPTIX_DEBUG"))
     fprintf(stderr, "[moptix] node format probe (%dx%d paths): 128-byte nodes %llu steps %llu triangle tests, 64-byte %llu / %llu -> %d\n", w, h,

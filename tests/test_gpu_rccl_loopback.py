@@ -81,14 +81,15 @@ def test_cli_spawn_ends_the_other_ranks_when_one_fails(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("split", ["tile", "sample"])
-def test_bench_py_two_ranks_on_one_gpu(split):
+@pytest.mark.parametrize("split,pipeline", [("tile", "0"), ("sample", "0"), ("tile", "1")])
+def test_bench_py_two_ranks_on_one_gpu(split, pipeline):
     """bench.py's N > 1 body on the GPU: two ranks under torch.distributed.run (gloo for the control plane, both on device 0, the frame's
     collective through the loop-back transport).  One JSON line from rank 0 with the per-rank diagnosis VERDICT r3 asked for; the line
     says itself that it is test plumbing."""
     import json
     e = _env()
     e["MOPTIX_BENCH_BACKEND"] = "gloo"; e["MOPTIX_BENCH_DEVICE"] = "0"
+    e["MOPTIX_BENCH_PIPELINE"] = pipeline      # "1": two frames in flight = two contexts with a communicator each per rank (the default from 8 ranks on)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         e.pop(k, None)
     sys.path.insert(0, REPO)
@@ -103,6 +104,7 @@ def test_bench_py_two_ranks_on_one_gpu(split):
     d = json.loads(lines[0])
     r = d["config"]["ranks"]
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["split"] == split and "TEST PLUMBING" in d["config"]["parallelism"]
+    assert d["config"]["pipeline"] == (pipeline == "1")
     assert len(r["kernel_ms_per_frame"]) == 2 and min(r["kernel_ms_per_frame"]) > 0 and r["comm_ranks_seen"] == 2
     assert len(r["collective_ms_per_frame"]) == 2 and max(r["collective_ms_per_frame"]) > 0
     assert len(r["rays_per_frame"]) == 2 and sum(r["rays_per_frame"]) == d["config"]["rays_per_frame"]
