@@ -195,9 +195,10 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
     # what the counters say limits this kernel: the vector ALUs.  binding_frac = share of all SIMD-cycles with a vector instruction in the pipe
     # (SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x cycles), PMC pass of this device code); null until such a pass exists for this workload
     head["binding"] = "valu_issue"
-    head["binding_frac"] = traffic.get("valu_active_frac") if traffic else None
-    head["binding_source"] = ("vector pipes busy (SQ_ACTIVE_INST_VALU, replayed from the committed PMC passes of this device code); issue rate against the measured "
-                              "ceiling in `valu_issue`; NOTEBOOK.md round 5 has the experiments that say neither look-ups nor bytes bind it")
+    head["binding_frac"] = min(1.0, traffic["valu_active_frac"]) if traffic and traffic.get("valu_active_frac") else None
+    head["binding_source"] = ("vector pipes busy: SQ_ACTIVE_INST_VALU x 4 / (1,024 SIMDs x cycles), replayed from the committed PMC passes of this device code (the counter "
+                              "sums the waves' own time with a vector instruction in flight, so dense code with four waves per SIMD reads above 1: capped); the issue "
+                              "RATE against the measured ceiling is in `valu_issue`; NOTEBOOK.md round 5 has the experiments that say neither look-ups nor bytes bind it")
     head.update({
         "gather_peak_GBps": round(gpeak, 1) if gpeak else None, "gather_frac": round(achieved_gbs / gpeak, 4) if gpeak else None,
         "gather_peak_source": GATHER_CEILING_FILE + " (tools/micro/gather.hip: dependent per-lane gathers of %d-B records, 3.1 MB table, best over occupancies)" % node_bytes,

@@ -11,18 +11,25 @@ out = sys.argv[1]
 for cfg in ("c2", "c4", "c5"):
     log = os.path.join(out, cfg + "_kt.log")
     line = [l for l in open(log).read().splitlines() if "per render" in l] if os.path.exists(log) else []
+    bl = os.path.join(out, "line_%s.json" % cfg)
+    if not line and os.path.exists(bl):
+        import json
+        try:
+            d = json.loads(open(bl).read()); line = ["%s: %.1f Mrays/s, %.3f ms per step (bench.py, un-profiled)" % (d["config"]["workload"], d["value"], d["ms_per_step"])]
+        except Exception:
+            pass
     print("== %s: %s" % (cfg, line[-1] if line else "(no timing line)"))
-    for f in glob.glob(os.path.join(out, cfg + "_kt", "**", "*kernel_stats.csv"), recursive=True):
+    for f in glob.glob(os.path.join(out, cfg + "_kt", "**", "*kernel_stats.csv"), recursive=True) + glob.glob(os.path.join(out, cfg, "kt", "**", "*kernel_stats.csv"), recursive=True):
         for i, row in enumerate(csv.reader(open(f))):
             if i == 0 or "pt_" in row[0] or "k_reduce" in row[0]:
                 print("   " + ", ".join(c[:60] for c in row[:7]))
     per = {}
     for p in ("sq", "ta", "fetch", "write", "l2"):
-        for f in glob.glob(os.path.join(out, "%s_%s" % (cfg, p), "**", "*counter_collection.csv"), recursive=True):
+        for f in glob.glob(os.path.join(out, "%s_%s" % (cfg, p), "**", "*counter_collection.csv"), recursive=True) + glob.glob(os.path.join(out, cfg, p, "**", "*counter_collection.csv"), recursive=True):
             agg, cnt = collections.defaultdict(float), collections.Counter()
             for r in csv.DictReader(open(f)):
                 n = r.get("Kernel_Name", "")
-                if not re.search(r"pt_(queue|packet|mega)kernel<false", n):
+                if not re.search(r"pt_(queue|packet|mega)kernel(_lean)?<false", n):
                     continue
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
             for k in agg:
