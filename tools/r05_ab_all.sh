@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 5: the A/B experiments of NOTEBOOK.md in one run (experiment libraries built with make EXTRA=... LIBNAME=...; see the header lines)
+# round 5: the A/B experiments of NOTEBOOK.md in one run (experiment libraries built with make EXTRA=... LIBNAME=...; see the header lines).
+# The source changes of the experiments that were NOT kept are recorded in profiles/r05_experiment_patches.txt; their macros no longer exist in csrc/.
 O=gpurun_out/r05d; mkdir -p $O
 {
 echo "# libmoptix_base.so = round 4's node step (EXTRA=-DPT_NO_SIGNED_FETCH at a4e2eff); libmoptix.so = shipped; _s8 = -DPT_PK_STACKN=8; _t40 = + -DPT_PK_TOPN=40 (top of the tree in LDS);"
