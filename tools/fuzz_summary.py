@@ -19,7 +19,7 @@ for path in sys.argv[1:]:
             shown.append(path.split("/")[-1] + ": " + line.strip())
 print("# tools/gpu_fuzz.py: every case renders a random scene / size / sample count / rank's share with the per-lane kernel (variant 0,")
 print("# leaves of 4, Karras tree) and again under random scheduler, tree and node-format options, twice (the second time with the tile")
-print("# history); the accumulators must be bit-identical.  A mismatch is replayed on the reference's tree: equal there = tree-dependent")
+print("# history); the accumulators must be bit-identical.  A mismatch is replayed with the per-lane kernel on the CANDIDATE's own tree: equal there = tree-dependent")
 print("# grazing hit (DESIGN.md section 2), else a scheduler MISMATCH.")
 print("cases %d: %s" % (sum(verdicts.values()), ", ".join("%s %d" % kv for kv in sorted(verdicts.items()))))
 print("\nby scene / kernel that ran / node format / shadow rule:")

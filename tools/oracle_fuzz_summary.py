@@ -1,6 +1,6 @@
 """Summary of tools/gpu_oracle_fuzz.py logs: python tools/oracle_fuzz_summary.py gpurun_out/ofuzz/*.txt > profiles/rNN_oracle_fuzz.txt"""
 import re, sys, collections
-n = collections.Counter(); rays = collections.Counter(); worst = collections.defaultdict(float); bad = []
+n = collections.Counter(); rays = collections.Counter(); worst = collections.defaultdict(float); bad = []; tree = []
 for path in sys.argv[1:]:
     for line in open(path):
         m = re.match(r"case\s+\d+\s+(\S+)\s+.*rule (\d) ran \((\d), (\d+)\): rmse (\S+) rays (\d+) / (\d+) closest hits (\d+) / (\d+) .*-> (\w+)", line.strip())
@@ -8,15 +8,21 @@ for path in sys.argv[1:]:
             continue
         scene, rule, var, fmt, e, r, ro, c, co, verdict = m.groups()
         k = (scene, "variant %s" % var, "rule %s" % rule)
-        n[k] += 1; rays[k] += int(r); worst[k] = max(worst[k], float(e))
-        if verdict != "ok":
+        n[k] += 1; rays[k] += int(r); worst[k] = max(worst[k], float(e) if verdict == "ok" else 0.0)      # worst RMSE of the identical cases
+        if verdict == "TREE":
+            tree.append(line.strip())
+        elif verdict != "ok":
             bad.append(line.strip())
 print("# tools/gpu_oracle_fuzz.py: the product path (C ABI, default options; kernel variant drawn from {library's choice, 3, 4}) against the")
 print("# oracle on random scene kinds / frame sizes / sample counts / seeds / shadow rules.  Per case the RMSE of the per-sample mean must be")
 print("# <= 2e-6 and the counts of rays and of closest hits must be EQUAL to the oracle's.")
-print("cases %d, rays compared %d, not ok %d, worst rmse %.2e\n" % (sum(n.values()), sum(rays.values()), len(bad), max(worst.values())))
+print("# The one accepted exception: a TREE-DEPENDENT grazing hit (DESIGN.md section 2) -- proved per case: the CPU build of the kernel code gives the GPU's")
+print("# counts and image on the device's tree, and the GPU gives exactly the oracle's on another tree of the same triangles.")
+print("cases %d, rays compared %d, tree-dependent grazing hits %d, not ok %d\n" % (sum(n.values()), sum(rays.values()), len(tree), len(bad)))
 print("  %-20s %-10s %-7s %6s %14s %10s" % ("scene", "kernel", "shadows", "cases", "rays", "worst rmse"))
 for k in sorted(n):
     print("  %-20s %-10s %-7s %6d %14d %10.2e" % (k + (n[k], rays[k], worst[k])))
+for t in tree:
+    print("TREE-DEPENDENT: " + t)
 for b in bad:
     print("NOT OK: " + b)
