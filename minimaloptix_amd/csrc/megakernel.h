@@ -31,6 +31,9 @@ struct LaunchArgs {
   int unitShift;                    // log2 of the slots per history unit: 6 = 8x8 tile, 0 = pixel
   const int* tileOrder;             // unit visited i-th (device, nItems >> unitShift entries) or nullptr = raster order
   unsigned int* tileCost;           // per unit: deepest path seen so far (device) or nullptr
+#ifdef PT_EVLOG
+  unsigned long long* evLog;        // experiment build (packetkernel.hip PT_EV): [0] events so far, [1..] the events
+#endif
 };
 constexpr int kDeepPath = 8;        // paths at least this deep are recorded in tileCost
 

@@ -250,6 +250,12 @@ int read_stats(moptix_context c, moptix_stats* stats) {
     fprintf(stderr, "[moptix] wave time: batch %.1f%% refill %.1f%% node %.1f%% leaf %.1f%% finish %.1f%% (steps %llu, cycles/wave %.3g)\n",
             100 * h[16] / tt, 100 * h[17] / tt, 100 * h[18] / tt, 100 * h[19] / tt, 100 * h[20] / tt, h[9], tt);
     fprintf(stderr, "[moptix] idle spins %llu\n", h[14]);
+    // absolute pass clocks (s_memtime ticks summed over the waves) with the launch's span in the same ticks per wave: for a launch that
+    // is one path walking (tools/gpu_lone_path.py) the passes are serial, so span - (batch + node + leaf) is what the scheduler costs
+    if (h[38] && h[36] != ~0ull && h[38] > h[36])
+      fprintf(stderr, "[moptix] pass ticks: batch %llu (load %llu run %llu store %llu) node %llu leaf %llu txn %llu lock %llu local %llu idle %llu | waves' time %llu over a span of %.1f us | "
+                      "batches %llu node runs %llu leaf passes %llu iterations %llu transactions %llu\n", h[16], h[28], h[29], h[30], h[18], h[19], h[26], h[25], h[24], h[27], h[21],
+              (double)(h[38] - h[36]) * 1e-2, h[11], h[39], h[22], h[32], h[31]);
     if (h[32]) fprintf(stderr, "[moptix] swap detail: local %.1f%% lock-wait %.1f%% txn %.1f%% idle %.1f%% | batch detail: load %.1f%% run %.1f%% store %.1f%% | "
                        "iterations %llu transactions %llu (cycles/iter %.0f)\n", 100 * h[24] / tt, 100 * h[25] / tt, 100 * h[26] / tt, 100 * h[27] / tt,
                        100 * h[28] / tt, 100 * h[29] / tt, 100 * h[30] / tt, h[32], h[31], tt / (double)h[32]);
@@ -419,6 +425,12 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     HIPCHK(c, hipMemsetAsync(c->dCounters.p + 36, 0xff, sizeof(unsigned long long) * 2, c->stream), "init min counters");
     a.counters = c->dCounters.p;
   }
+#ifdef PT_EVLOG      // experiment build only (packetkernel.hip PT_EV): the event log stands in for the counters of an UNCOUNTED launch
+  DevBuf<unsigned long long> evLog;
+  HIPCHK(c, evLog.ensure(65536 + 8), "alloc event log");      // always there: the kernel logs whenever it meets a path deeper than 100 bounces
+  HIPCHK(c, hipMemsetAsync(evLog.p, 0, sizeof(unsigned long long) * (65536 + 8), c->stream), "zero event log");
+  a.evLog = evLog.p;
+#endif
   c->seedStaging.assign(seeds, seeds + nSeeds);   // lives in the context: the copy below may still be in flight when an async render returns
   HIPCHK(c, c->dSeeds.upload(c->seedStaging, c->stream), "upload seeds");
 
@@ -444,6 +456,15 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     const bool last = first + perPass >= nSeeds;
     if (!last || blocking) { if ((rc = moptix_sync(c)) != MOPTIX_OK) return rc; }
   }
+#ifdef PT_EVLOG
+  if (blocking && !counted && getenv("MOPTIX_EVLOG")) {
+    std::vector<unsigned long long> h(65536);
+    HIPCHK(c, hipMemcpy(h.data(), evLog.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost), "read event log");
+    FILE* f = fopen(getenv("MOPTIX_EVLOG"), "wb");
+    if (f) { fwrite(h.data(), sizeof(unsigned long long), (size_t)std::min<unsigned long long>(h[0], 65000ull) + 1, f); fclose(f); }
+  }
+  evLog.release();
+#endif
   if (blocking && a.tileCost && getenv("MOPTIX_DEBUG")) {       // how the deepest-path history is distributed over the tiles
     std::vector<unsigned int> cost((size_t)historyUnits);
     HIPCHK(c, hipMemcpy(cost.data(), c->dTileCost.p, sizeof(unsigned int) * cost.size(), hipMemcpyDeviceToHost), "read tile cost");

@@ -268,6 +268,16 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
   constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
   __shared__ PoolLds<NS> sPool[SHARED ? 1 : kWaves];
   __shared__ WavePriv<NS> sPriv[kWaves];
+  // -DPT_EVLOG (tools/gpu_lone_path.py EVLOG=1; not part of the product build): once a visit has seen a path deeper than 100 bounces, every
+  // wave of that workgroup logs its passes with 100 MHz stamps -- the timeline of one capped path walking in an idle machine
+#ifdef PT_EVLOG
+  __shared__ int sEvOn;
+  if (threadIdx.x == 0) sEvOn = 0;
+#define PT_EV(code, val) do { if (sEvOn && (threadIdx.x & 63) == 0) { const unsigned long long i_ = atomicAdd(a.evLog, 1ull); \
+    if (i_ < 65000ull) a.evLog[1 + i_] = (__builtin_amdgcn_s_memrealtime() << 24) | (((unsigned long long)(val) & 0xffffull) << 8) | ((unsigned long long)(threadIdx.x >> 6) << 4) | (unsigned long long)(code); } } while (0)
+#else
+#define PT_EV(code, val) do { } while (0)
+#endif
 
   SceneView scv = a.scene;
   scv.shadowNearest = NEAR ? 1 : 0;                 // compile-time constant from here on
@@ -452,6 +462,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     const SceneView& sc = scl;
     const bool have = slot >= 0;
     if (CNT) { leafPasses++; leafLanes += (uint32_t)__popcll(__ballot(have)); }
+    PT_EV(7, __popcll(__ballot(have)));
     pendSlot = slot; pendDest = DEST_NONE;
     // slot records written by earlier passes of this wave (other lanes) or published by other waves: the stores
     // of the previous pass were left in flight, so they are ordered here, where their latency has already elapsed
@@ -549,6 +560,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     // through a queue transaction, whose release fence (txn_end) covers these stores: no wait here, the store
     // latency overlaps with the bookkeeping that follows.
     if constexpr (!SHARED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    PT_EV(8, 0);
   };
 
   // ---- shading / regeneration batch: run the path state machine for the popped slots ----
@@ -558,6 +570,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     const SceneView& sc = scl;
     const bool have = slot >= 0;
     if (CNT) { batches++; batchLanes += (uint32_t)__popcll(__ballot(have)); }
+    PT_EV(1, __popcll(__ballot(have)));
     PT_SUB0();
     pendSlot = slot; pendDest = DEST_NONE;
     PathState ps; Trav res;
@@ -577,6 +590,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       const int nSh = (fl >> kPendShift) & 3;          // 0 for a slot that waits for a work item (flags are cleared then)
       const bool hadAux = (fl & kHasAux) != 0;         // its shadow rays were traced by the borrowed slots
       const i4 ctl = slot_load(&cs->ctl);
+#ifdef PT_EVLOG
+      if (ctl.y >= 100) sEvOn = 1;
+#endif
       const v4 thrIn = slot_load(&cs->thr), radIn = slot_load(&cs->rad);
       v4 wh = mk4(0.f, 0.f, 0.f, 0.f), wb = mk4(1.f, 1.f, 1.f, 1.f);
       v4 wp[kPacketShadows], wa[kPacketShadows];
@@ -613,6 +629,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     }
     const SlotSink sink{ cold, slot >= 0 ? slot : 0, W.nodeA, W.nodeB, W.stack, &ps, sc.rootRef, axp };
     if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBLoad); }
+#ifdef PT_EVLOG
+    __builtin_amdgcn_s_waitcnt(0); PT_EV(2, 0);
+#endif
     for (;;) {
       if (have && ps.mode == M_NEW_SAMPLE) {
         if (CNT) {      // finish-time histogram (1 ms buckets): how many samples end when, and how deep they were
@@ -647,6 +666,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       }
     }
     if (CNT) { __builtin_amdgcn_s_waitcnt(0); PT_SUB(tBRun); }
+#ifdef PT_EVLOG
+    __builtin_amdgcn_s_waitcnt(0); PT_EV(3, 0);
+#endif
     bool useAux = false;
     if (have) {
       SlotCold* cw = at32(cold, slot);
@@ -733,6 +755,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     }
     if constexpr (!SHARED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     PT_SUB(tBStore);
+    PT_EV(4, __popcll(__ballot(useAux)));
   };
 
   unsigned int guard = 0;
@@ -798,6 +821,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     } else if (starving || flush) {
       // =========================== queue transaction ===========================
       PT_SUB(tLocal);
+      PT_EV(9, nActive);
       txn_begin();
       for (int d = 0; d < 2; d++) {
         const int q = Q_SHADE + d;
@@ -819,6 +843,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       if (pass == 1 || pass == 2) mySlot = q_pop(pass == 1 ? Q_SHADE : Q_GEN, true);
       txn_end();
       if (pass == 0) mySlot = leaf_pop();
+      PT_EV(10, pass + 1);
       PT_SUB(tTxn);
       // =========================================================================
     } else PT_SUB(tLocal);
@@ -832,7 +857,14 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     if (CNT) { nodeRuns++; ringBacklog += (unsigned long long)nqCount; leafBacklog += (unsigned long long)lqCount; }
     {
       SlotStack st = make_stack(ns >= 0 ? ns : 0);
+      PT_EV(5, nActive);
+#ifdef PT_EVLOG
+      int evSteps = 0;
+#endif
       for (;;) {
+#ifdef PT_EVLOG
+        evSteps++;
+#endif
         const bool atNode = ns >= 0 && ntv.node >= 0 && ntv.node != kTravDone;
         const unsigned long long m = __ballot(atNode);
         const int n = __popcll(m);
@@ -840,6 +872,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         if (CNT) { nodeSteps++; nodeLanes += (uint32_t)n; }
         if (atNode) trav_node_step<CNT, N64>(sc, nray, ntv, st, ct);
       }
+#ifdef PT_EVLOG
+      PT_EV(6, evSteps - 1);
+#endif
     }
     PT_STAMP(tNode);
   }

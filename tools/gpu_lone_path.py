@@ -1,0 +1,89 @@
+"""One path walking to the depth cap in an otherwise empty GPU: launch time / bounces = the latency of a bounce (us).
+
+The launch's drain is a few capped paths (Material.cu:29 / MinimalOptiX.h:85: 256 bounces) finishing while the
+machine idles; what a bounce costs THERE is what this measures.  A (tile, launch seed) of the benchmark frame that holds a capped
+path is found by timing (a tile rendered alone through the tile split: rank t of as many ranks as the frame has tiles), then that
+one 64-sample launch is timed under option sets, and once with the counting build (MOPTIX_DEBUG=1 prints the pass clocks).
+
+  FOUND=gpurun_out/lone.json   cache of the (tile, seed) pairs found (written by the scan, read by later runs / other libraries)
+  OPTSETS="aux_depth=0;aux_depth=1"   extra option sets (the default set always runs)
+  SCENE=coffee|dining_standin|million_standin
+"""
+import json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+import numpy as np
+import minimaloptix_amd as M
+
+kind = os.environ.get("SCENE", "coffee")
+kw = dict(iarg=1000000) if kind == "million_standin" else dict(iarg=6) if kind == "dining_standin" else {}
+W, H = 1920, 1080
+hs = M.HostScene("file:coffee" if kind == "coffee" else kind, W, H, **kw)
+nT = ((W + 7) // 8) * ((H + 7) // 8)
+found_path = os.environ.get("FOUND", os.path.join(REPO, "gpurun_out", "lone_%s.json" % kind))
+want = int(os.environ.get("WANT", "3"))
+
+
+def fresh(opts=""):
+    ctx = M.Context(0)
+    ctx.set_option("kernel_variant", 4); ctx.set_option("watchdog_ms", 60000)
+    if kind == "coffee": ctx.set_option("node_format", 64)
+    for o in opts.split(","):
+        if "=" in o:
+            k, v = o.split("="); ctx.set_option(k, int(v))
+    ctx.load(hs)
+    return ctx
+
+
+def timed(ctx, seeds, reps=3):
+    best = 1e9
+    for _ in range(reps):
+        ctx.kernel_time(reset=True); ctx.render(seeds); ms, _n = ctx.kernel_time(); best = min(best, ms)
+    return best
+
+
+if os.path.exists(found_path):
+    found = json.load(open(found_path))
+else:
+    ctx = fresh()
+    seeds16 = M.launch_seeds(16)
+    found, t0 = [], time.time()
+    stride = int(os.environ.get("STRIDE", "37"))
+    for t in range(int(os.environ.get("START", "5000")), nT, stride):
+        ctx.set_partition(t, nT)
+        ms = timed(ctx, seeds16, 1)
+        if ms > 6.0:
+            per = [(timed(ctx, seeds16[i:i + 1], 1), i) for i in range(16)]
+            per.sort(reverse=True)
+            # exactly one slow seed: a lone capped path (two in one launch would share the machine)
+            if per[0][0] > 6.0 and per[1][0] < 2.0:
+                found.append(dict(tile=t, seed_index=per[0][1], ms=per[0][0]))
+                print("tile %d seed %d: %.2f ms (next %.2f)" % (t, per[0][1], per[0][0], per[1][0]), flush=True)
+                if len(found) >= want: break
+        if time.time() - t0 > 240: break
+    os.makedirs(os.path.dirname(found_path), exist_ok=True)
+    json.dump(found, open(found_path, "w"))
+    ctx.close()
+if not found:
+    print("no lone capped path found"); sys.exit(1)
+
+if os.environ.get("EVLOG"):                        # a -DPT_EVLOG library (MOPTIX_DEVICE_LIB): the timeline of the first pair found, see tools/evlog_timeline.py
+    ctx = fresh(os.environ.get("OPTS", "")); f = found[0]
+    ctx.set_partition(f["tile"], nT)
+    seeds = M.launch_seeds(1, first=f["seed_index"])
+    ctx.render(seeds)
+    os.environ["MOPTIX_EVLOG"] = os.environ["EVLOG"]
+    ctx.kernel_time(reset=True); ctx.render(seeds); print("event-log launch: %.3f ms" % ctx.kernel_time()[0])
+    sys.exit(0)
+sets = [""] + [s for s in os.environ.get("OPTSETS", "").split(";") if s]
+for opts in sets:
+    ctx = fresh(opts)
+    for f in found:
+        seeds = M.launch_seeds(1, first=f["seed_index"])
+        ctx.set_partition(f["tile"], nT)
+        ms = timed(ctx, seeds, 5)
+        st = ctx.render_counted(seeds)
+        hits = int(st.closestHits)
+        print("[%s] tile %d seed %d: %.3f ms, %d closest hits of 64 paths, %d rays -> %.1f us per bounce of the capped path (counting build: span %.3f ms)"
+              % (opts or "default", f["tile"], f["seed_index"], ms, hits, st.rays, 1e3 * ms / 257.0, ctx.get_option("counted_span_us") / 1e3), flush=True)
+    ctx.close()
