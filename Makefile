@@ -22,7 +22,7 @@ BUILD    ?= build
 HIPFLAGS := $(EXTRA) --offload-arch=$(ARCH) -O3 -fno-slp-vectorize -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -include cstring
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -mavx2 -mfma -Wall -Wno-unused-function -Wno-unknown-pragmas
 
-DEV_SRCS := $(CSRC)/moptix_api.hip $(CSRC)/megakernel.hip $(CSRC)/queuekernel.hip $(CSRC)/queuekernel_lean.hip $(CSRC)/packetkernel.hip $(CSRC)/lbvh.hip
+DEV_SRCS := $(CSRC)/moptix_api.hip $(CSRC)/megakernel.hip $(CSRC)/queuekernel.hip $(CSRC)/queuekernel_lean.hip $(CSRC)/packetkernel.hip $(CSRC)/drainkernel.hip $(CSRC)/lbvh.hip
 DEV_OBJS := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(DEV_SRCS))
 DEV_HDRS := $(wildcard $(CSRC)/*.h) include/moptix.h
 HOST_SRCS := $(HOST)/obj_loader.cpp $(HOST)/scene_file.cpp $(HOST)/scenes.cpp $(HOST)/standin_scenes.cpp $(HOST)/image_read.cpp $(HOST)/jpeg_read.cpp \

@@ -96,7 +96,7 @@ struct moptix_context_t {
   DevBuf<TriUV> dFaceUV; DevBuf<float> dTexels; DevBuf<DevTexture> dTextures;
   LbvhResult bvh;
   DevBuf<float> dAccum; float* accumBound = nullptr; size_t accumPixels = 0;
-  DevBuf<int> dSeeds; DevBuf<int> dWork; DevBuf<unsigned long long> dCounters; DevBuf<int> dOverflow; DevBuf<uint8_t> dRgb8;
+  DevBuf<int> dSeeds; DevBuf<int> dWork; DevBuf<unsigned long long> dCounters; DevBuf<int> dOverflow; DevBuf<int> dDrainList; DevBuf<uint8_t> dRgb8;
   DevBuf<uint8_t> dPoolCold; DevBuf<float> dSampleBuf;
 
   int rank = 0, nRanks = 1;
@@ -124,6 +124,7 @@ struct moptix_context_t {
   int optShadowRule = 1;             // 1 = a shadow ray is decided by its nearest any-hit surface (default), 0 = SURVEY A2's order-independent rule
   bool variantExplicit = false;      // kernel_variant was set by the caller: no automatic choice
   int optSlotsInUse = -1;            // -1 = chosen per launch from its size
+  int optDrainBelow = 64;            // a workgroup of the packet kernel with this many paths left hands them to the drain kernel (0 = off)
   int optAuxDepth = 16;              // variant 4: depth from which a path's shadow rays get slots of their own (0 = off)
   double kernelMs = 0.0, reduceMs = 0.0; uint64_t nLaunches = 0;
   bool asyncPending = false;
@@ -363,6 +364,16 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     }
     HIPCHK(c, c->dPoolCold.ensure(packetkernel_cold_bytes(nBlocks)), "alloc path pool");
     a.poolCold = c->dPoolCold.p;
+    // the launch's last paths are finished by the drain kernel (drainkernel.hip; "drain_below" = 0 keeps them in the packet kernel)
+    // (not under "shadow_rule" 0 in a scene with glass: there a shadow ray's attenuation is a PRODUCT over the glass surfaces it crosses, taken in
+    // traversal order, and the drain kernel's order is not the packet kernel's)
+    bool glassMaterial = false;
+    for (const DevMaterial& m : c->mats) if (m.kind == MAT_DISNEY && m.brdfType == BRDF_GLASS) glassMaterial = true;
+    a.drainBelow = (glassMaterial && !a.scene.shadowNearest) ? 0 : c->optDrainBelow;
+    if (a.drainBelow > 0) {
+      HIPCHK(c, c->dDrainList.ensure(drain_list_ints(nBlocks, a.drainBelow)), "alloc drain list");
+      a.drainList = c->dDrainList.p; a.drainCap = nBlocks * a.drainBelow;
+    }
   } else if (useQueue && leanQueue) {
     // no tree to walk (queuekernel_lean.hip): a fourth workgroup per CU instead of path slots and stack entries
     if (c->optBlocksPerCU == 3) nBlocks = c->numCUs * 4;
@@ -445,7 +456,9 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
                                                (size_t)historyUnits, 0, 32, c->stream), "sort tiles");
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
+    if (usePacket && a.drainBelow > 0) HIPCHK(c, hipMemsetAsync(a.drainList, 0, 4 * sizeof(int), c->stream), "zero drain list");
     if (usePacket) HIPCHK(c, launch_packetkernel(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch packet megakernel");
+    if (usePacket && a.drainBelow > 0) HIPCHK(c, launch_drainkernel(c->stream, a, c->numCUs, counted, c->optFastShading != 0), "launch drain kernel");
     else if (useQueue && leanQueue) HIPCHK(c, launch_queuekernel_lean(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch queue megakernel (lean)");
     else if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch queue megakernel");
     else HIPCHK(c, launch_megakernel(c->stream, a, nBlocks, counted), "launch megakernel");
@@ -640,7 +653,7 @@ int moptix_destroy(moptix_context c) {
   lbvh_free(&c->bvh);
   c->dPoolCold.release(); c->dSampleBuf.release();
   c->dTileCost.release(); c->dTileCostSorted.release(); c->dTileOrder.release(); c->dTileIota.release(); c->dSortTmp.release();
-  c->dAccum.release(); c->dSeeds.release(); c->dWork.release(); c->dCounters.release(); c->dOverflow.release(); c->dRgb8.release();
+  c->dAccum.release(); c->dSeeds.release(); c->dWork.release(); c->dCounters.release(); c->dOverflow.release(); c->dDrainList.release(); c->dRgb8.release();
   c->dTileSend.release(); c->dTileRecv.release();
   if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -914,6 +927,7 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "auto_packet")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "auto_packet in {0,1}"); c->optAutoPacket = value; }
   else if (!strcmp(name, "analytic_queue")) { if (value < -1 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "analytic_queue in {-1,0,1}"); c->optAnalyticQueue = value; }
   else if (!strcmp(name, "aux_depth")) { if (value < 0 || value > 100000) return fail(c, MOPTIX_ERR_INVALID, "aux_depth in [0,100000]"); c->optAuxDepth = value; }
+  else if (!strcmp(name, "drain_below")) { if (value < 0 || value > 64) return fail(c, MOPTIX_ERR_INVALID, "drain_below in [0,64]"); c->optDrainBelow = value; }
   else if (!strcmp(name, "slots_in_use")) { if (value < -1 || value > 1024) return fail(c, MOPTIX_ERR_INVALID, "slots_in_use in [-1,1024]"); c->optSlotsInUse = value; }
   else if (!strcmp(name, "builder")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "builder in {0,1}"); if (value != c->optBuilder) c->accelBuilt = false; c->optBuilder = value; }
   else if (!strcmp(name, "fast_shading")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "fast_shading in {0,1}"); c->optFastShading = value; }
@@ -944,6 +958,7 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "builder")) *value = c->optBuilder;
   else if (!strcmp(name, "aux_depth")) *value = c->optAuxDepth;
   else if (!strcmp(name, "slots_in_use")) *value = c->optSlotsInUse;
+  else if (!strcmp(name, "drain_below")) *value = c->optDrainBelow;
   else if (!strcmp(name, "analytic_queue")) *value = c->optAnalyticQueue;
   else if (!strcmp(name, "auto_packet")) *value = c->optAutoPacket;
   else if (!strcmp(name, "kernel_variant_used")) *value = c->lastVariant;

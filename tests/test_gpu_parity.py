@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 
 RMSE_TOL = 1e-3        # BASELINE.json north_star
 RMSE_TIGHT = 2e-6      # what the arithmetic contract actually delivers (float association only)
+DRAIN_DEFAULT = 64     # option drain_below as moptix_create leaves it (csrc/moptix_api.hip optDrainBelow)
 
 CASES = [
     ("spheres", dict(farg=0.5), (160, 90), 4),
@@ -448,6 +449,9 @@ def test_node_format_changes_the_work_never_the_image(gpu_ctx, scene, kw):
     res = {}
     try:
         gpu_ctx.set_option("kernel_variant", 4)
+        # the packet kernel's own walk is what this test counts: the drain kernel's frontier visits a ray's boxes in whatever order its atomics
+        # settle, so ITS node and triangle counts vary from run to run (its results do not: test_drain_kernel_changes_nothing)
+        gpu_ctx.set_option("drain_below", 0)
         for fmt in (128, 64, 0, 0):
             gpu_ctx.set_option("node_format", fmt)
             gpu_ctx.load(hs); gpu_ctx.accum_clear()
@@ -457,7 +461,7 @@ def test_node_format_changes_the_work_never_the_image(gpu_ctx, scene, kw):
             assert used == (fmt or used) and used in (64, 128)
             res.setdefault(fmt, []).append((gpu_ctx.accum_read(), st, used))
     finally:
-        gpu_ctx.set_option("node_format", 0); gpu_ctx.set_option("kernel_variant", -1)
+        gpu_ctx.set_option("node_format", 0); gpu_ctx.set_option("kernel_variant", -1); gpu_ctx.set_option("drain_below", DRAIN_DEFAULT)
     (a128, s128, _), (a64, s64, _) = res[128][0], res[64][0]
     assert np.array_equal(a128.view(np.uint32), a64.view(np.uint32))
     assert (s128.rays, s128.shadowRays, s128.closestHits) == (s64.rays, s64.shadowRays, s64.closestHits)
@@ -512,3 +516,35 @@ def test_a_tree_too_wide_for_the_node_grid_keeps_the_128_byte_nodes(gpu_ctx, tmp
         assert np.array_equal(g4.view(np.uint32), gpu_ctx.accum_read().view(np.uint32))
     finally:
         gpu_ctx.set_option("node_format", 0); gpu_ctx.set_option("kernel_variant", -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,kw,size", [("file:coffee", {}, (320, 180)), ("coffee_pot_standin", {}, (200, 112)), ("dining_standin", dict(iarg=2), (200, 112)),
+                                           ("million_standin", dict(iarg=3000), (200, 112))])
+def test_drain_kernel_changes_nothing(gpu_ctx, scene, kw, size):
+    """The launch's last paths are finished by csrc/drainkernel.hip (a wave per up to sixteen paths, all 64 lanes on one shared frontier of (node, ray)
+    entries; a ray's nearest hit kept as a 64-bit (t, primitive) key under an LDS atomic minimum).  What a ray reports is defined without
+    the traversal's order (rule D5), so handing paths over -- earlier or later (drain_below), whole launches of them in these small frames --
+    must leave every accumulator bit, ray count and closest-hit count where the packet kernel alone (drain_below 0) puts them.  The frames are
+    small on purpose: most workgroups start below the threshold and the drain kernel renders most of the image."""
+    hs = M.HostScene(scene, size[0], size[1], **kw)
+    seeds = M.launch_seeds(16)
+    out = {}
+    try:
+        gpu_ctx.set_option("kernel_variant", 4)
+        for db in (0, 4, 64):
+            gpu_ctx.set_option("drain_below", db)
+            gpu_ctx.load(hs); gpu_ctx.accum_clear()
+            st = gpu_ctx.render_counted(seeds)
+            if gpu_ctx.get_option("kernel_variant_used") != 4:
+                pytest.skip("scene outside the packet kernel's limits")
+            out[db] = (gpu_ctx.accum_read(), st)
+            gpu_ctx.accum_clear(); gpu_ctx.render(seeds)                       # the uncounted instantiation
+            assert np.array_equal(gpu_ctx.accum_read().view(np.uint32), out[db][0].view(np.uint32))
+    finally:
+        gpu_ctx.set_option("drain_below", DRAIN_DEFAULT); gpu_ctx.set_option("kernel_variant", -1)
+    a0, s0 = out[0]
+    for db in (4, 64):
+        a, st = out[db]
+        assert np.array_equal(a.view(np.uint32), a0.view(np.uint32)), "drain_below %d changed the image" % db
+        assert (st.rays, st.shadowRays, st.closestHits, st.samples) == (s0.rays, s0.shadowRays, s0.closestHits, s0.samples)

@@ -15,6 +15,15 @@ for o in os.environ.get("OPTS", "").split(","):
 if os.environ.get("PART"):                      # PART=r/n: rank r's share of an n-way tile split
     r_, n_ = os.environ["PART"].split("/"); ctx.set_partition(int(r_), int(n_))
 ctx.load(hs)
+if os.environ.get("COLD"):                      # the FIRST frame of a context: no depth history orders its work (kernel code already loaded)
+    r_, n_ = (os.environ.get("PART") or "0/1").split("/")
+    ctx.set_partition(0, 3); ctx.load(hs); ctx.render(seeds[:2])          # another partition: loads the kernels, and the switch back forgets the history
+    cold = []
+    for rep in range(3):
+        ctx.set_partition(0, 3); ctx.load(hs); ctx.render(seeds[:1])
+        ctx.set_partition(int(r_), int(n_)); ctx.load(hs)
+        ctx.accum_clear(); ctx.kernel_time(reset=True); ctx.render(seeds); cold.append(ctx.kernel_time()[0])
+    print("cold frames (no history), spp %d: %s ms" % (spp, " ".join("%.2f" % m for m in cold)), flush=True)
 for _ in range(int(os.environ.get("WARM", "0"))):   # history for the tile order
     ctx.accum_clear(); ctx.render(seeds)
 ctx.accum_clear(); st = ctx.render_counted(seeds)
