@@ -14,6 +14,14 @@ A step = one frame of the metric's configuration: coffee.obj scene (168,193 tria
 to rank 0; --split sample gives rank r the launches i = r mod N over the whole frame and sums the accumulators with
 one reduce -- BASELINE.json configs[4]'s decomposition).  Scene, BVH and seeds are resident in HBM before the timed
 region.  Prints ONE JSON line on rank 0.
+
+N > 1 (no multi-GPU node has been available to this project: the first run on one must explain itself whatever happens):
+  * pre-flight: every communicator carries one collective under a 30 s deadline before anything is timed; if that fails on any rank
+    with the non-blocking communicator, all ranks fall back to a blocking one once; if it fails again rank 0 prints a JSON line with
+    "error" and every rank's diagnosis and the process exits 3 (fresh processes only, never a re-exec);
+  * from 8 ranks on BOTH modes are timed, K steps each: one frame at a time, then two frames in flight (two contexts, two
+    communicators per rank); `config.modes` carries both, `value` is the better one, `config.mode` says which.  A mode that fails is
+    reported under its name and the other one stands.  Below 8 ranks: one frame at a time (two in flight loses there).
 """
 import argparse
 import json
@@ -30,9 +38,18 @@ sys.path.insert(0, REPO)
 
 NODE_BYTES = 64             # the node record the packet kernel fetches on coffee (csrc/pt_types.h Node64; get_option "node_format_used" says which)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
-GATHER_CEILING_FILE = os.path.join("profiles", "r03_gather_ceiling.txt")    # output of tools/micro/gather on MI355X
-VALU_CEILING_FILE = os.path.join("profiles", "r04_valu_ceiling.txt")        # output of tools/micro/valu_issue on MI355X
-PIPELINE_FROM_RANKS = 8     # two frames in flight by default from this many ranks on (GpuFrame)
+def _latest(pattern, fallback):
+    """The newest committed round of a micro-benchmark's output (profiles/rNN_<pattern>)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_" + pattern)))
+    return os.path.relpath(hits[-1], REPO) if hits else fallback
+
+
+GATHER_CEILING_FILE = _latest("gather_ceiling.txt", os.path.join("profiles", "r03_gather_ceiling.txt"))    # output of tools/micro/gather on MI355X
+VALU_CEILING_FILE = _latest("valu_ceiling.txt", os.path.join("profiles", "r04_valu_ceiling.txt"))          # output of tools/micro/valu_issue on MI355X
+PIPELINE_FROM_RANKS = int(os.environ.get("MOPTIX_BENCH_PIPELINE_FROM", "8"))     # from this many ranks on the two-frames-in-flight mode is timed as well (after the one-frame mode)
+PREFLIGHT_TIMEOUT_MS = int(os.environ.get("MOPTIX_BENCH_PREFLIGHT_MS", "30000"))
+COMM_TIMEOUT_MS = 120000
 KERNEL_WAVES_PER_SIMD = 3   # what the trace kernel's 168 registers and 53 KB of LDS allow (csrc/packetkernel.hip)
 
 
@@ -151,7 +168,7 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
     `valu_issue`: what the counters say binds the kernel -- the issue rate of the vector ALUs at the three waves per SIMD its
     registers and LDS allow.  achieved = SQ_INSTS_VALU per launch (PMC pass of THIS device code, profiles/traffic.json) / the
     launch duration measured here; peak = the chip's measured rate for independent v_fma_f32 at three waves per SIMD
-    (profiles/r04_valu_ceiling.txt, tools/micro/valu_issue.hip; v_min / v_max / v_cvt / v_cmp / v_cndmask issue at about
+    (VALU_CEILING_FILE: the newest committed profiles/rNN_valu_ceiling.txt, tools/micro/valu_issue.hip; v_min / v_max / v_cvt / v_cmp / v_cndmask issue at about
     half of it, `peak_half_rate_class`); useful_lane_frac = frac x the share of lanes active in an issued instruction.
     `live_fields` / `replayed_fields` say which numbers were measured in this run and which come from the committed passes."""
     launch_s = launch_ms * 1e-3
@@ -219,8 +236,9 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
                         "valu_issue.achieved / frac / useful_lane_frac (numerator replayed, launch duration live)"],
         "replayed_fields": ["traffic", "hbm_frac", "hbm_frac_if_128B_reads", "fabric_GBps", "fabric_bytes_per_ray", "tcc_hit_rate", "l1_address_unit_busy_frac",
                             "l1_lookups_per_cu_clock", "valu_issue.instructions_per_ray / lane_utilisation / valu_active_frac (profiles/traffic.json, "
-                            "rocprofv3 --pmc passes of this device code: source_hash-gated, null otherwise)", "peaks (profiles/r04_valu_ceiling.txt, "
-                            "profiles/r03_gather_ceiling.txt, HBM spec)"],
+                            "rocprofv3 --pmc passes of this device code: source_hash-gated, null otherwise)", "peaks (%s, %s, HBM spec)" % (VALU_CEILING_FILE, GATHER_CEILING_FILE)],
+        # no hardware counter is read inside this run: everything under replayed_fields comes from the committed --pmc passes
+        "pmc_live": False,
     })
     return head
 
@@ -333,26 +351,96 @@ class GpuFrame:
         # GPU (profiles/r05_scaling_emulation.txt): an 8-way share 43.4 -> 39.7 ms (89 % -> 98 % of ideal), a 4-way share
         # 77.1 -> 76.2 ms, the whole frame 310 -> 323 ms (worse: hence not below 8 ranks).  Never run beside RCCL's kernels on a real
         # multi-GPU node; the collectives have a deadline (csrc/moptix_api.hip comm_wait).
+        # Which modes this run times (run_rank): MOPTIX_BENCH_PIPELINE=1 / 0 forces two frames in flight / one frame at a time only;
+        # otherwise one frame at a time, and from PIPELINE_FROM_RANKS ranks on two in flight AS WELL (the better one is `value`).
         pl = os.environ.get("MOPTIX_BENCH_PIPELINE", "")
-        self.pipeline = pl == "1" or (pl == "" and self.part_n >= PIPELINE_FROM_RANKS)
+        if pl == "1":
+            self.mode_list = ["two_in_flight"]
+        elif pl == "0" or self.part_n < PIPELINE_FROM_RANKS or world == 1:
+            self.mode_list = ["one_frame"]
+        else:
+            self.mode_list = ["one_frame", "two_in_flight"]
+        self.M, self.hs, self.local = M, hs, local
+        self.pipeline = False
         self.ctxs, self.accums = [self.ctx], [self.accum]
-        if self.pipeline:
-            ctx2 = M.Context(local)
-            if not self.sample_split:
-                ctx2.set_partition(self.part_rank, self.part_n)
-            ctx2.load(hs)
-            accum2 = torch.zeros(H * W * 3, dtype=torch.float32, device=self.device)
-            ctx2.accum_bind(accum2.data_ptr())
-            self.ctxs.append(ctx2); self.accums.append(accum2)
-        self.pending = [False] * len(self.ctxs)
+        self.pending = [False]
         self.frame_no = 0
         self.collective_s, self.collectives = 0.0, 0
         # the frame's collective runs behind the C ABI on the context's own RCCL communicator (moptix_gather_tiles /
         # moptix_reduce_frame); MOPTIX_BENCH_FORCE_DIST=1 brings a one-rank communicator up on a 1-GPU box
         self.use_comm = world > 1 or os.environ.get("MOPTIX_BENCH_FORCE_DIST") == "1"
         if self.use_comm:
-            for c in self.ctxs:
-                D.comm_init(c, rank, world, self.device)
+            D.comm_init(self.ctx, rank, world, self.device)
+
+    def modes(self):
+        return list(self.mode_list)
+
+    def set_mode(self, mode):
+        """"one_frame": a frame is rendered and collected before the next starts.  "two_in_flight": a second context (own stream, own
+        accuBuffer, own communicator) renders the alternate frames; created here, the first time the mode is asked for (collective:
+        every rank makes its second communicator at the same point)."""
+        self.flush()
+        self.pipeline = mode == "two_in_flight"
+        if self.pipeline and len(self.ctxs) == 1:
+            a, torch = self.a, self.torch
+            ctx2 = self.M.Context(self.local)
+            if not self.sample_split:
+                ctx2.set_partition(self.part_rank, self.part_n)
+            if getattr(self, "comm_blocking", 0):
+                ctx2.set_option("comm_blocking", 1)
+            ctx2.load(self.hs)
+            accum2 = torch.zeros(a.height * a.width * 3, dtype=torch.float32, device=self.device)
+            ctx2.accum_bind(accum2.data_ptr())
+            self.ctxs.append(ctx2); self.accums.append(accum2); self.pending.append(False)
+            if self.use_comm:
+                self.D.comm_init(ctx2, self.rank, self.world, self.device)
+        self.frame_no = 0
+
+    def preflight(self, which=None):
+        """One collective per communicator under a short deadline, before anything is timed: a run that cannot communicate says so
+        within PREFLIGHT_TIMEOUT_MS instead of after comm_timeout_ms inside the timed region.  Returns None or what went wrong."""
+        if not self.use_comm:
+            return None
+        for j, c in enumerate(self.ctxs):
+            if which is not None and j != which:
+                continue
+            try:
+                c.set_option("comm_timeout_ms", PREFLIGHT_TIMEOUT_MS)
+                self.accums[j].zero_(); self.sync()
+                self.collect(j)
+                c.set_option("comm_timeout_ms", COMM_TIMEOUT_MS)
+            except Exception as e:
+                return "communicator %d: %s" % (j, e)
+        return None
+
+    def reinit_comm(self, blocking):
+        """Every rank drops its communicators and makes new ones (collective), blocking or not."""
+        self.comm_blocking = 1 if blocking else 0
+        for c in self.ctxs:
+            try:
+                c.comm_destroy()
+            except Exception:
+                pass
+            c.set_option("comm_blocking", self.comm_blocking)
+            self.D.comm_init(c, self.rank, self.world, self.device)
+
+    def comm_kind(self):
+        if not self.use_comm:
+            return None
+        return "non-blocking (ncclCommInitRankConfig, calls polled against comm_timeout_ms)" if self.ctx.get_option("comm_nonblocking_used") else "blocking (ncclCommInitRank)"
+
+    def first_frame(self):
+        """A context's FIRST frame: no depth history orders its work yet, so the launch ends with the deepest paths walking alone
+        (csrc/drainkernel.hip takes them over).  Trace-kernel ms of one frame rendered like that (the kernel code is loaded: one
+        small launch first); the history is dropped again afterwards so that the counted launch that follows is a first frame, too."""
+        self.ctx.render(self.seeds[:1])
+        self.ctx.set_option("forget_history", 1)
+        self.accum.zero_(); self.sync()
+        self.ctx.kernel_time(reset=True)
+        self.ctx.render(self.seeds)
+        ms, _n = self.ctx.kernel_time()
+        self.ctx.set_option("forget_history", 1)
+        return ms
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -364,7 +452,11 @@ class GpuFrame:
         st = self.ctx.render_counted(self.seeds)
         px = a.width * a.height if self.sample_split else len(self.D.tile_pixel_indices(a.width, a.height, self.part_rank, self.part_n))
         self.node_bytes = self.ctx.get_option("node_format_used") if self.ctx.get_option("kernel_variant_used") == 4 else 128
-        # the counting launch stamps its own timeline: first wave in -> last wave out, and how much of that came after the last work item
+        # the counting launch stamps its own timeline: first wave in -> last wave out (drain kernel included), and how much of that came
+        # after the last work item.  The first call describes a context's first frame, a later one the frames the timed region renders
+        if not hasattr(self, "counted_tail_first_ms"):
+            self.counted_tail_first_ms = self.ctx.get_option("counted_tail_us") * 1e-3
+            self.counted_span_first_ms = self.ctx.get_option("counted_span_us") * 1e-3
         self.counted_span_ms = self.ctx.get_option("counted_span_us") * 1e-3
         self.counted_tail_ms = self.ctx.get_option("counted_tail_us") * 1e-3
         nS, nQ, nF = self.hs_sizes
@@ -427,6 +519,7 @@ class GpuFrame:
         """The reference compiles its programs with -use_fast_math (utils_host.cpp:30-32).  `value` is the exact mode (bit
         parity with the oracle); the opt-in approximate BRDF arithmetic ("fast_shading": same rays, weights within ~1e-6)
         is timed beside it on one GPU, outside the timed region, and reported as a separate field."""
+        self.flush()
         if self.world != 1 or self.emu > 1 or self.pipeline:
             return None
         ctx, accum = self.ctx, self.accum
@@ -464,7 +557,7 @@ class GpuFrame:
             par = "sample-split x%d (rank r renders launches i = r mod %d) + RCCL reduce" % (world, world)
         else:
             par = "tile-split x%d (8x8 tiles dealt round-robin, rotating per group) + RCCL gather" % world
-        return par + (", two frames in flight" if self.pipeline else "")
+        return par
 
     def traffic(self):
         a = self.a
@@ -527,36 +620,109 @@ def run_rank(a, frame_cls=GpuFrame):
             dist.barrier()
         fr.sync()
 
+    def everyone(text):
+        """What every rank has to say (None = nothing), on every rank, over the control plane."""
+        if not (use_dist and world > 1):
+            return [text]
+        got = [None] * world
+        dist.all_gather_object(got, text)
+        return got
+
+    def give_up(what, per_rank_text):
+        """The run cannot produce a number: rank 0 still prints ONE JSON line that says why, every rank exits 3."""
+        if rank == 0:
+            print(json.dumps({"metric": "Mrays/s (primary+bounce+shadow rays traced per second)", "value": None, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
+                              "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                              "error": what, "config": {"workload": workload_text(a), "split": a.split if world > 1 else None,
+                                                        "ranks": {"diagnosis": per_rank_text}}}), flush=True)
+        if use_dist:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        raise SystemExit(3)
+
+    # ---- pre-flight: one collective per communicator under a short deadline; one fall-back to a blocking communicator ----
+    comm_note = None
+    if hasattr(fr, "preflight"):
+        said = everyone(fr.preflight())
+        if any(said):
+            comm_note = "pre-flight failed with the %s communicator (%s); every rank made a blocking one" % (
+                "non-blocking" if not getattr(fr, "comm_blocking", 0) else "blocking", "; ".join("rank %d: %s" % (i, t) for i, t in enumerate(said) if t))
+            try:
+                fr.reinit_comm(blocking=True)
+                said = everyone(fr.preflight())
+            except Exception as e:
+                said = everyone(str(e))
+            if any(said):
+                give_up("the ranks cannot complete a collective (pre-flight, %d ms deadline; non-blocking and blocking communicator both tried)" % PREFLIGHT_TIMEOUT_MS,
+                        ["rank %d: %s" % (i, t or "ok") for i, t in enumerate(said)])
+
+    first_ms = fr.first_frame() if hasattr(fr, "first_frame") and world == 1 and not os.environ.get("MOPTIX_BENCH_PIPELINE") else None
     my_rays, my_bytes = fr.count()
     tot = torch.tensor([float(my_rays), float(my_bytes)], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tot)
     total_rays, total_bytes = float(tot[0].item()), float(tot[1].item())
 
-    for _ in range(a.warmup):
-        fr.step()
-    fr.flush()
-    fr.reset_kernel_time()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        fr.step()
-    fr.flush()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    kms, nlaunch, reduce_ms = fr.kernel_times()
-    # per-rank diagnosis of an N > 1 run (one driver run has to explain itself): each rank's mean trace-kernel ms per frame, the
-    # drain of its counted launch, its collective's wall ms per frame and its ray count, gathered on every rank
-    mine = torch.tensor([kms / max(1, a.steps), getattr(fr, "counted_tail_ms", -1.0), getattr(fr, "counted_span_ms", -1.0),
-                         getattr(fr, "collective_s", 0.0) * 1e3 / max(1, a.steps), float(my_rays)], dtype=torch.float64, device=dev)
-    per_rank = [mine.clone() for _ in range(world)]
-    if use_dist and world > 1:
-        dist.all_gather(per_rank, mine)
-    per_rank = [[float(x) for x in t.tolist()] for t in per_rank]
+    # ---- the timed region, once per mode: W untimed frames, then exactly K frames between barrier + synchronize, MAX over ranks ----
+    modes = fr.modes() if hasattr(fr, "modes") else ["one_frame"]
+    results = {}
+    for mi, mode in enumerate(modes):
+        failed = None
+        try:
+            if hasattr(fr, "set_mode"):
+                fr.set_mode(mode)
+                if mode == "two_in_flight" and hasattr(fr, "preflight"):
+                    failed = fr.preflight(which=1)                      # the second communicator, made just now
+            if not failed:
+                for _ in range(a.warmup):
+                    fr.step()
+                fr.flush()
+                if mi == 0 and a.warmup > 0 and hasattr(fr, "first_frame"):
+                    fr.count()                                          # the counted launch again, in the state the timed frames are in
+                fr.reset_kernel_time()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    fr.step()
+                fr.flush()
+                barrier()
+                dt = time.perf_counter() - t0
+        except Exception as e:                                          # a collective that hit its deadline (MOPTIX_ERR_COMM), a HIP error ...
+            failed = "%s: %s" % (type(e).__name__, e)
+        said = everyone(failed)
+        if any(said):
+            results[mode] = {"error": "; ".join("rank %d: %s" % (i, t) for i, t in enumerate(said) if t)}
+            if mi + 1 < len(modes) or not any("ms_per_step" in r for r in results.values()):
+                # the communicators of a failed mode are gone (aborted): nothing further can be timed with them
+                break
+            continue
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        kms, nlaunch, reduce_ms = fr.kernel_times()
+        # per-rank diagnosis of an N > 1 run (one driver run has to explain itself): each rank's mean trace-kernel ms per frame, the
+        # drain of its counted launch, its collective's wall ms per frame and its ray count, gathered on every rank
+        mine = torch.tensor([kms / max(1, a.steps), getattr(fr, "counted_tail_ms", -1.0), getattr(fr, "counted_span_ms", -1.0),
+                             getattr(fr, "collective_s", 0.0) * 1e3 / max(1, a.steps), float(my_rays), getattr(fr, "counted_tail_first_ms", -1.0)], dtype=torch.float64, device=dev)
+        per_rank = [mine.clone() for _ in range(world)]
+        if use_dist and world > 1:
+            dist.all_gather(per_rank, mine)
+        per_rank = [[float(x) for x in t.tolist()] for t in per_rank]
+        results[mode] = {"ms_per_step": dt / a.steps * 1e3, "dt": dt, "kms": kms, "nlaunch": nlaunch, "reduce_ms": reduce_ms, "per_rank": per_rank}
+    good = {m: r for m, r in results.items() if "ms_per_step" in r}
+    if not good:
+        give_up("no mode could be timed", ["%s: %s" % (m, r.get("error")) for m, r in results.items()])
+    mode = min(good, key=lambda m: good[m]["ms_per_step"])
+    best = good[mode]
+    dt, kms, nlaunch, reduce_ms, per_rank = best["dt"], best["kms"], best["nlaunch"], best["reduce_ms"], best["per_rank"]
+    if hasattr(fr, "set_mode") and len(modes) > 1:
+        try:
+            fr.set_mode("one_frame")
+        except Exception:
+            pass
     fast = None if a.no_fast_leg else fr.fast_leg(total_rays)
 
     if rank == 0:
@@ -574,6 +740,14 @@ def run_rank(a, frame_cls=GpuFrame):
         headline = a.scene == "file:coffee" and (W, H, a.spp) == (1920, 1080, 256)
         if headline and world == 1:
             roof["other_configs"] = other_configs(REPO)      # BASELINE configs 2, 4, 5: their committed lines' rates and fractions
+
+        def mode_summary(r):
+            if "ms_per_step" not in r:
+                return r
+            pr = r["per_rank"]
+            return {"ms_per_frame": round(r["ms_per_step"], 3), "value_Mrays_s": round(total_rays / (r["dt"] / a.steps) / 1e6, 2),
+                    "kernel_ms_per_frame_min_max": [round(min(x[0] for x in pr), 3), round(max(x[0] for x in pr), 3)],
+                    "collective_ms_per_frame_max": round(max(x[3] for x in pr), 3)}
         out = {
             "metric": "Mrays/s (primary+bounce+shadow rays traced per second, %s)" % ("coffee.obj 1920x1080 256spp" if headline else "%s %dx%d %dspp" % (a.scene, W, H, a.spp)),
             "value": round(total_rays / (dt / a.steps) / 1e6, 2), "unit": "Mrays/s",
@@ -581,19 +755,28 @@ def run_rank(a, frame_cls=GpuFrame):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": getattr(fr, "data", "reference scene scenes/coffee (168,193 triangles; Mesh010 missing upstream), synthetic seed schedule tea16(i,0)" if a.scene == "file:coffee"
                             else "stand-in scene authored by this project (minimaloptix_amd/host/standin_scenes.cpp, scenes.cpp), synthetic seed schedule tea16(i,0)"),
+            "pmc_live": False,
             "config": dict({"workload": workload_text(a),
                             "scene": a.scene, "width": W, "height": H, "spp": a.spp, "rays_per_frame": int(total_rays),
-                            "parallelism": fr.parallelism(), "split": a.split if world > 1 else None,
-                            "pipeline": bool(getattr(fr, "pipeline", False)), "ms_per_frame": round(ms_per_step, 3),
+                            "parallelism": fr.parallelism() + (", two frames in flight" if mode == "two_in_flight" else ""), "split": a.split if world > 1 else None,
+                            # which of the timed modes `value` is, and every mode that was timed (K steps each) or tried
+                            "mode": mode, "pipeline": mode == "two_in_flight", "modes": {m: mode_summary(r) for m, r in results.items()},
+                            "communicator": fr.comm_kind() if hasattr(fr, "comm_kind") else None, "communicator_note": comm_note,
+                            "ms_per_frame": round(ms_per_step, 3),
+                            # a context's first frame (no depth history orders its work yet): trace-kernel ms, next to the timed frames' mean
+                            "first_frame_kernel_ms": round(first_ms, 3) if first_ms is not None else None,
                             "source_hash": source_hash(REPO),
                             "ranks": {"kernel_ms_per_frame": [round(r[0], 3) for r in per_rank],
                                       "kernel_ms_per_frame_min_max": [round(min(r[0] for r in per_rank), 3), round(max(r[0] for r in per_rank), 3)],
                                       "counted_launch_tail_ms": [round(r[1], 3) for r in per_rank], "counted_launch_span_ms": [round(r[2], 3) for r in per_rank],
+                                      "counted_launch_tail_ms_first_frame": [round(r[5], 3) for r in per_rank],
                                       "collective_ms_per_frame": [round(r[3], 3) for r in per_rank], "rays_per_frame": [int(r[4]) for r in per_rank],
                                       "comm_ranks_seen": (fr.ctx.get_option("comm_ranks") if getattr(fr, "use_comm", False) else 1) if hasattr(fr, "ctx") else world,
-                                      "note": "kernel ms: HIP events round the trace kernel on the launch stream; tail / span: s_memrealtime stamps of the counting "
-                                              "launch (work items ran out -> last wave out; first wave in -> last wave out); collective: wall time of "
-                                              "moptix_gather_tiles / moptix_reduce_frame incl. its stream synchronisation"}}, **d),
+                                      "note": "kernel ms: HIP events round the trace kernel (packet + drain kernel) on the launch stream; tail / span: s_memrealtime stamps of a "
+                                              "counting launch (work items ran out -> last wave of the drain kernel out; first wave in -> last wave out): "
+                                              "counted_launch_tail_ms in the state of the timed frames (after the warm-up: the depth history orders the work), "
+                                              "..._first_frame for a context's first launch; collective: wall time of moptix_gather_tiles / moptix_reduce_frame incl. "
+                                              "its stream synchronisation"}}, **d),
             "roofline": roof,
         }
         if fast is not None:

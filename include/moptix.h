@@ -187,15 +187,21 @@ int moptix_set_partition(moptix_context ctx, int32_t rank, int32_t nRanks);
 /* Multi-GPU collectives (new; SURVEY 8e, north_star "RCCL gather over xGMI"): one process per GPU, the context owns an
  * RCCL communicator.  One rank calls moptix_comm_unique_id (ncclGetUniqueId) and hands the 128 bytes to the others by
  * whatever the host has (a file, MPI, torch.distributed, a socket); every rank then calls moptix_comm_init
- * (ncclCommInitRank: collective, blocks until all nRanks have called it).
+ * (collective: returns when all nRanks have called it).  Where the library offers it the communicator is NON-BLOCKING
+ * (ncclCommInitRankConfig with config.blocking = 0; option "comm_blocking" = 1 asks for plain ncclCommInitRank): every RCCL call
+ * then returns at once -- ncclInProgress while the library is still at work on the host, e.g. bringing a peer's connections up --
+ * and this layer polls the communicator's state against "comm_timeout_ms".  With a blocking communicator a peer that is alive but
+ * never makes its call holds the caller INSIDE ncclSend / ncclGroupEnd, where no deadline can reach.
  *   moptix_gather_tiles : tile split (moptix_set_partition(rank, nRanks) as the communicator's) -- every other rank packs its
  *                         tiles and ncclSend()s them to dstRank, which receives them in one group and writes them into its
  *                         accuBuffer on the device: dstRank then holds the whole frame, bit-identical to a one-GPU render.
  *   moptix_reduce_frame : sample split -- ncclReduce(sum) of the accuBuffers into dstRank's.
- * Both block until the data has landed -- at most "comm_timeout_ms" (option; default 120 s): a collective that has not completed
- * by then (a peer died or never called), or whose communicator reports an asynchronous error, is ABORTED (ncclCommAbort) and the
- * call returns MOPTIX_ERR_COMM; the host should exit (the context itself stays usable as a one-rank context).  With a
- * communicator of one rank they are no-ops.
+ * Both block until the data has landed -- at most "comm_timeout_ms" (option; default 120 s), host side (non-blocking communicator:
+ * the call has not settled) and device side (its kernels have not finished) alike: a collective that has not completed by then (a peer
+ * died or never called), or whose communicator reports an asynchronous error, is ABORTED (ncclCommAbort) and the call returns
+ * MOPTIX_ERR_COMM; the host should exit.  The context stays usable as a one-rank context -- unless the dead collective's kernels
+ * never leave its stream (a library without ncclCommAbort: the communicator is abandoned, not destroyed, and if the stream is still
+ * busy after 10 s every later call on the context returns MOPTIX_ERR_COMM).  With a communicator of one rank they are no-ops.
  * moptix_pack_tiles / moptix_unpack_tiles are the device-side halves of the gather (rank r's tiles of the accuBuffer <->
  * a dense buffer of moptix_packed_tile_floats(nRanks) floats in work-item order), exposed so that the partition can be
  * tested on one GPU. */
@@ -254,11 +260,18 @@ int moptix_unpack_tiles(moptix_context ctx, int32_t rank, int32_t nRanks, const 
  *                      1: hardware reciprocal / square-root approximations there (the reference itself is built with
  *                      -use_fast_math, utils_host.cpp:30-32): same rays, BRDF weights within ~1e-6, default kernel only
  *   "watchdog_ms"      wall-clock bound of one render kernel (default 600000); a pass cut short is not accumulated
- *   "comm_timeout_ms"  deadline of moptix_gather_tiles / moptix_reduce_frame (default 120000): when the collective has not completed by
- *                      then, or the communicator reports an asynchronous error, the communicator is aborted and the call returns
- *                      MOPTIX_ERR_COMM instead of blocking the rank for good
+ *   "comm_timeout_ms"  deadline of moptix_comm_init / moptix_gather_tiles / moptix_reduce_frame (default 120000): when the call has not
+ *                      settled on the host or its kernels have not completed by then, or the communicator reports an asynchronous
+ *                      error, the communicator is aborted and the call returns MOPTIX_ERR_COMM instead of blocking the rank for good
+ *   "forget_history"   (write-only, any value) drop the per-pixel depth history that orders the work items ("tile_major"): the next launch
+ *                      is ordered like the first one of a context -- what a single-frame render sees
+ *   "comm_blocking"    1 = moptix_comm_init makes a blocking communicator even where a non-blocking one is available (default 0)
+ *   "drain_below"      variant 4: a workgroup of the trace kernel that is down to this many paths (default 64, 0 = never) hands them
+ *                      to the drain kernel (csrc/drainkernel.hip: a wave per up to 16 paths, all lanes on one frontier) at their next
+ *                      packet boundary and leaves; same image bits, ray and hit counts either way -- the node / triangle-test counts
+ *                      of a counted launch then vary a little from run to run (the frontier's visiting order follows its atomics)
  * read-only (get_option): "kernel_variant_used", "node_format_used", "path_slots", "num_cus", "comm_ranks" (size of the context's
- *   communicator, 0 without one), and after moptix_render_counted
+ *   communicator, 0 without one), "comm_nonblocking_used" (1: that communicator is non-blocking), and after moptix_render_counted
  *   "counted_span_us" (first wave in -> last wave out of the trace kernel) / "counted_tail_us" (the part of it after the last
  *   work item was handed out: the launch's drain; -1 for the per-lane kernel)
  * Unknown names -> MOPTIX_ERR_INVALID. */

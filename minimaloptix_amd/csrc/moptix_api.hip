@@ -120,6 +120,9 @@ struct moptix_context_t {
   int optAutoPacket = 1;
   int lastVariant = -1;              // what the last render ran (get_option "kernel_variant_used")
   int countedSpanUs = -1, countedTailUs = -1;   // last counted launch: first wave in -> last wave out, and the part of it after the last work item was handed out
+  int optCommBlocking = 0;           // 1 = plain ncclCommInitRank even where a non-blocking communicator is available
+  bool commNonBlocking = false;      // the communicator was made with config.blocking = 0 (calls may return ncclInProgress: comm_settle)
+  bool poisoned = false;             // a dead collective's kernels are still on the stream (comm_teardown): every call fails from here on
   int optCommTimeoutMs = 120000;     // deadline of a collective's completion (comm_wait); the first collective of a communicator also sets its links up
   int optShadowRule = 1;             // 1 = a shadow ray is decided by its nearest any-hit surface (default), 0 = SURVEY A2's order-independent rule
   bool variantExplicit = false;      // kernel_variant was set by the caller: no automatic choice
@@ -230,6 +233,7 @@ int choose_node_format(moptix_context c) {
 
 int check_ready(moptix_context c) {
   if (!c) return fail(nullptr, MOPTIX_ERR_INVALID, "null context");
+  if (c->poisoned) return fail(c, MOPTIX_ERR_COMM, "this context is unusable: kernels of an aborted collective never left its stream");
   if (!c->haveParams) return fail(c, MOPTIX_ERR_STATE, "moptix_set_params has not been called");
   if (!c->accelBuilt) return fail(c, MOPTIX_ERR_STATE, "moptix_build_accel has not been called since the scene changed");
   return MOPTIX_OK;
@@ -538,6 +542,10 @@ struct RcclApi {
   // optional (used by comm_wait when the library has them): error state of a communicator without blocking, and tearing one down
   // while its kernels are still on the stream
   decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr; decltype(&ncclCommAbort) CommAbort = nullptr;
+  // optional: a NON-BLOCKING communicator (config.blocking = 0).  With a blocking one ncclSend / ncclGroupEnd / ncclReduce may sit inside
+  // the library while the links to a peer are set up -- a peer that is alive but never calls blocks the host there, where no deadline of
+  // ours can reach.  A non-blocking communicator returns ncclInProgress instead and the state is polled (comm_settle)
+  decltype(&ncclCommInitRankConfig) CommInitRankConfig = nullptr;
   bool ok = false; std::string error;
 };
 // MOPTIX_RCCL_LIB names another library with the same nine entry points (a transport plug point; tests/rccl_loopback is a
@@ -564,6 +572,7 @@ RcclApi load_rccl() {
   api.ok = all;
   api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
   api.CommAbort = (decltype(api.CommAbort))dlsym(h, "ncclCommAbort");
+  api.CommInitRankConfig = (decltype(api.CommInitRankConfig))dlsym(h, "ncclCommInitRankConfig");
   return api;
 }
 RcclApi& rccl() {
@@ -583,6 +592,44 @@ int ncclFail(moptix_context c, ncclResult_t r, const char* what) {
 // ABORTED (ncclCommAbort makes its kernels leave), the stream is given a bounded time to drain, and the call returns
 // MOPTIX_ERR_COMM: the host is expected to exit (bench.py, class MinimalOptiX and dist.py raise).  The context keeps working
 // as a one-rank context; a new communicator needs moptix_comm_init again.
+// Tears a communicator down whose kernels or host-side operations cannot complete.  With ncclCommAbort its kernels leave and its
+// resources go; WITHOUT it the communicator is leaked -- ncclCommDestroy waits for outstanding work, i.e. for the very thing that
+// does not come.  The stream gets a bounded time to drain; if it has not by then the context is marked unusable (every later call
+// returns MOPTIX_ERR_COMM): kernels of a dead collective still sit on its stream.
+int comm_teardown(moptix_context c, const char* what, const std::string& why) {
+  using clock = std::chrono::steady_clock;
+  bool leaked = false;
+  if (c->comm) {
+    if (rccl().CommAbort) (void)rccl().CommAbort(c->comm); else leaked = true;
+    c->comm = nullptr; c->commRank = 0; c->commRanks = 1; c->commNonBlocking = false;
+  }
+  const auto t1 = clock::now();                     // the aborted kernels leave; never wait for them without a bound either
+  while (hipStreamQuery(c->stream) == hipErrorNotReady && clock::now() - t1 < std::chrono::seconds(10)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  const bool busy = hipStreamQuery(c->stream) == hipErrorNotReady;
+  if (busy) c->poisoned = true;
+  return fail(c, MOPTIX_ERR_COMM, std::string(what) + ": " + why + (leaked ? "; the communicator was abandoned (this library has no ncclCommAbort)" : "; the communicator was aborted") +
+                                  (busy ? "; its kernels are still on the stream: this context is unusable from here on" : ""));
+}
+// After a call on a NON-BLOCKING communicator: ncclInProgress means the library is still working on it in the background (setting links
+// up, waiting for the peer's side of a connection); nothing else may be issued on the communicator until that has settled.  Polled
+// against the same deadline as the device side ("comm_timeout_ms"); a hard error or the deadline tears the communicator down.
+int comm_settle(moptix_context c, ncclResult_t r, const char* what) {
+  using clock = std::chrono::steady_clock;
+  if (r == ncclSuccess) return MOPTIX_OK;
+  if (r != ncclInProgress || !c->commNonBlocking || !c->comm) return ncclFail(c, r, what);
+  const auto t0 = clock::now();
+  const auto deadline = std::chrono::milliseconds(c->optCommTimeoutMs);
+  for (unsigned spin = 0;; spin++) {
+    ncclResult_t st = ncclSuccess;
+    const ncclResult_t q = rccl().CommGetAsyncError(c->comm, &st);
+    if (q != ncclSuccess) return comm_teardown(c, what, std::string("ncclCommGetAsyncError: ") + rccl().GetErrorString(q));
+    if (st == ncclSuccess) return MOPTIX_OK;
+    if (st != ncclInProgress) return comm_teardown(c, what, std::string("communicator reports ") + rccl().GetErrorString(st));
+    if (clock::now() - t0 > deadline)
+      return comm_teardown(c, what, "still in progress on the host after comm_timeout_ms = " + std::to_string(c->optCommTimeoutMs) + " (a peer is alive but has not made its call)");
+    if (spin < 4096) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
+  }
+}
 int comm_wait(moptix_context c, const char* what) {
   using clock = std::chrono::steady_clock;
   const auto t0 = clock::now();
@@ -599,13 +646,7 @@ int comm_wait(moptix_context c, const char* what) {
     if (clock::now() - t0 > deadline) { why = "no completion within comm_timeout_ms = " + std::to_string(c->optCommTimeoutMs) + " (a peer is missing or late)"; break; }
     if (spin < 4096) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
   }
-  if (c->comm) {
-    if (rccl().CommAbort) (void)rccl().CommAbort(c->comm); else (void)rccl().CommDestroy(c->comm);
-    c->comm = nullptr; c->commRank = 0; c->commRanks = 1;
-  }
-  const auto t1 = clock::now();                     // the aborted kernels leave; never wait for them without a bound either
-  while (hipStreamQuery(c->stream) == hipErrorNotReady && clock::now() - t1 < std::chrono::seconds(10)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
-  return fail(c, MOPTIX_ERR_COMM, std::string(what) + ": " + why + "; the communicator was aborted");
+  return comm_teardown(c, what, why);
 }
 
 }  // namespace
@@ -935,6 +976,8 @@ int moptix_set_option(moptix_context c, const char* name, int32_t value) {
   else if (!strcmp(name, "shadow_rule")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "shadow_rule in {0,1}"); c->optShadowRule = value; }
   else if (!strcmp(name, "watchdog_ms")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "watchdog_ms >= 1"); c->optWatchdogMs = value; }
   else if (!strcmp(name, "comm_timeout_ms")) { if (value < 1) return fail(c, MOPTIX_ERR_INVALID, "comm_timeout_ms >= 1"); c->optCommTimeoutMs = value; }
+  else if (!strcmp(name, "forget_history")) { c->tileHistoryTiles = -1; }      // the next launch orders its work like a context's first (measurement of a cold frame)
+  else if (!strcmp(name, "comm_blocking")) { if (value < 0 || value > 1) return fail(c, MOPTIX_ERR_INVALID, "comm_blocking in {0,1}"); c->optCommBlocking = value; }
   else return fail(c, MOPTIX_ERR_INVALID, std::string("unknown option: ") + name);
   return MOPTIX_OK;
 }
@@ -952,6 +995,8 @@ int moptix_get_option(moptix_context c, const char* name, int32_t* value) {
   else if (!strcmp(name, "tile_major")) *value = c->optTileMajor;
   else if (!strcmp(name, "watchdog_ms")) *value = c->optWatchdogMs;
   else if (!strcmp(name, "comm_timeout_ms")) *value = c->optCommTimeoutMs;
+  else if (!strcmp(name, "comm_blocking")) *value = c->optCommBlocking;
+  else if (!strcmp(name, "comm_nonblocking_used")) *value = c->commNonBlocking ? 1 : 0;
   else if (!strcmp(name, "node_format")) *value = c->optNodeFormat;
   else if (!strcmp(name, "node_format_used")) *value = c->nodeFormatUsed;
   else if (!strcmp(name, "fast_shading")) *value = c->optFastShading;
@@ -1110,6 +1155,19 @@ int moptix_comm_init(moptix_context c, const uint8_t* id128, int32_t rank, int32
   HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
   if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
   ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+  c->commNonBlocking = false;
+  // Non-blocking where the library can do it and can also be polled and aborted ("comm_blocking" = 1 forces the plain form): every later
+  // call then returns at once, ncclInProgress while the library still works on it, and comm_settle polls that state against
+  // "comm_timeout_ms" -- a peer that is alive but never calls can no longer hold this rank inside ncclGroupEnd / ncclSend for good.
+  if (!c->optCommBlocking && rccl().CommInitRankConfig && rccl().CommGetAsyncError && rccl().CommAbort) {
+    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+    cfg.blocking = 0;
+    const ncclResult_t r = rccl().CommInitRankConfig(&c->comm, nRanks, id, rank, &cfg);
+    c->commNonBlocking = true; c->commRank = rank; c->commRanks = nRanks;
+    const int rc = comm_settle(c, r, "ncclCommInitRankConfig");
+    if (rc != MOPTIX_OK) { c->commNonBlocking = false; c->commRank = 0; c->commRanks = 1; return rc; }
+    return MOPTIX_OK;
+  }
   NCCLCHK(c, rccl().CommInitRank(&c->comm, nRanks, id, rank), "ncclCommInitRank");
   c->commRank = rank; c->commRanks = nRanks;
   return MOPTIX_OK;
@@ -1173,16 +1231,17 @@ int moptix_gather_tiles(moptix_context c, int32_t dstRank) {
     HIPCHK(c, c->dTileSend.ensure(cnt), "alloc tile staging");
     k_pack_tiles<<<grid, block, 0, c->stream>>>(accum_ptr(c), c->dTileSend.p, d);
     HIPCHK(c, hipGetLastError(), "pack tiles");
-    NCCLCHK(c, rccl().Send(c->dTileSend.p, cnt, ncclFloat, dstRank, c->comm, c->stream), "ncclSend");
+    if ((rc = comm_settle(c, rccl().Send(c->dTileSend.p, cnt, ncclFloat, dstRank, c->comm, c->stream), "ncclSend")) != MOPTIX_OK) return rc;
   } else {
     HIPCHK(c, c->dTileRecv.ensure(cnt * (size_t)n), "alloc tile staging");
     NCCLCHK(c, rccl().GroupStart(), "ncclGroupStart");
     ncclResult_t recvErr = ncclSuccess;
-    for (int r = 0; r < n && recvErr == ncclSuccess; r++)
+    for (int r = 0; r < n && (recvErr == ncclSuccess || recvErr == ncclInProgress); r++)
       if (r != dstRank) recvErr = rccl().Recv(c->dTileRecv.p + cnt * (size_t)r, cnt, ncclFloat, r, c->comm, c->stream);
     const ncclResult_t endErr = rccl().GroupEnd();           // always: a group left open would swallow every later call of this thread
-    if (recvErr != ncclSuccess) return ncclFail(c, recvErr, "ncclRecv");
-    if (endErr != ncclSuccess) return ncclFail(c, endErr, "ncclGroupEnd");
+    if (recvErr != ncclSuccess && recvErr != ncclInProgress) return ncclFail(c, recvErr, "ncclRecv");
+    // the receives are on the stream only once the group has settled (non-blocking communicator): the unpack kernels go behind them
+    if ((rc = comm_settle(c, endErr, "ncclGroupEnd")) != MOPTIX_OK) return rc;
     for (int r = 0; r < n; r++) {                            // the other ranks' tiles into this rank's accuBuffer
       if (r == dstRank) continue;
       TileDeal dr = d; dr.rank = r;
@@ -1201,8 +1260,8 @@ int moptix_reduce_frame(moptix_context c, int32_t dstRank) {
   if (rc != MOPTIX_OK) return rc;
   HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
   if ((rc = ensure_accum(c)) != MOPTIX_OK) return rc;
-  if (c->commRanks > 1)
-    NCCLCHK(c, rccl().Reduce(accum_ptr(c), accum_ptr(c), 3 * c->accumPixels, ncclFloat, ncclSum, dstRank, c->comm, c->stream), "ncclReduce");
+  if (c->commRanks > 1 && (rc = comm_settle(c, rccl().Reduce(accum_ptr(c), accum_ptr(c), 3 * c->accumPixels, ncclFloat, ncclSum, dstRank, c->comm, c->stream), "ncclReduce")) != MOPTIX_OK)
+    return rc;
   return c->commRanks > 1 ? comm_wait(c, "moptix_reduce_frame") : moptix_sync(c);
 }
 

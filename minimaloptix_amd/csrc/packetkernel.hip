@@ -788,7 +788,10 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       }
       nDone += localDone; localDone = 0;
       // the workgroup is down to its last paths: whatever comes back from its packet is handed to the drain kernel (hand_over)
-      if (a.drainBelow > 0 && NS - nDone <= a.drainBelow && qCount[Q_SHADE] + qCount[Q_GEN] > 0) pass = 5;
+#ifndef PT_HANDOVER
+#define PT_HANDOVER 1
+#endif
+      if (PT_HANDOVER && a.drainBelow > 0 && NS - nDone <= a.drainBelow && qCount[Q_SHADE] + qCount[Q_GEN] > 0) pass = 5;
       else if (qCount[Q_SHADE] >= 64) pass = 1;
       else if (qCount[Q_GEN] >= 64) pass = 2;
       else if (lqCount >= 64) pass = 0;

@@ -13,6 +13,12 @@
 // kernel on the caller's stream that spins until the communicator is aborted (ncclCommAbort raises a flag in host-mapped memory;
 // the kernel also gives up by itself after 30 s so that no test can hang the GPU).  libmoptix.so's deadline (comm_wait: poll the
 // stream, ncclCommGetAsyncError, ncclCommAbort) is tested against it (tests/test_gpu_rccl_loopback.py).
+//
+// MOPTIX_LOOPBACK_STUCK=2 models the OTHER place a missing call shows: on the host.  With a blocking communicator RCCL would sit inside
+// ncclGroupEnd / ncclSend while the links to the peer come up; libmoptix.so therefore makes its communicators non-blocking
+// (ncclCommInitRankConfig, config.blocking = 0), where the call returns ncclInProgress and ncclCommGetAsyncError keeps saying so.
+// Here: on a non-blocking communicator ncclGroupEnd / ncclSend / ncclReduce return ncclInProgress and the communicator's state stays
+// ncclInProgress until it is aborted -- libmoptix.so's comm_settle has to give up at its deadline.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -33,7 +39,9 @@ constexpr int kMaxRanks = 8;
 constexpr size_t kChunk = 1 << 20;      // bytes per mailbox
 struct Mailbox { std::atomic<uint32_t> full; uint32_t bytes; char pad[56]; char data[kChunk]; };
 struct Segment { std::atomic<uint32_t> arrived; char pad[60]; Mailbox box[kMaxRanks][kMaxRanks]; };
-struct Comm { int rank, n; Segment* seg; char name[64]; uint32_t* abortHost; uint32_t* abortDev; };
+struct Comm { int rank, n; Segment* seg; char name[64]; uint32_t* abortHost; uint32_t* abortDev; int blocking; int inProgress; };
+Comm* g_lastGrouped = nullptr;      // the communicator of the calls since ncclGroupStart (this transport's groups are one thread, one communicator)
+bool host_stuck(const Comm* c) { const char* e = getenv("MOPTIX_LOOPBACK_STUCK"); return e && e[0] == '2' && c && !c->blocking; }
 
 __global__ void k_stuck(const uint32_t* abortFlag, unsigned long long maxTicks) {      // a collective's kernel whose peer never arrives
   const unsigned long long t0 = wall_clock64();                                         // 100 MHz
@@ -100,7 +108,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   if (p == MAP_FAILED) return ncclSystemError;
   Comm* c = new Comm; c->rank = rank; c->n = nranks; c->seg = (Segment*)p;
   strncpy(c->name, id.internal, sizeof(c->name) - 1); c->name[sizeof(c->name) - 1] = 0;
-  c->abortHost = nullptr; c->abortDev = nullptr;
+  c->abortHost = nullptr; c->abortDev = nullptr; c->blocking = 1; c->inProgress = 0;
   if (hipHostMalloc((void**)&c->abortHost, 64, hipHostMallocMapped) == hipSuccess) {
     *c->abortHost = 0;
     if (hipHostGetDevicePointer((void**)&c->abortDev, c->abortHost, 0) != hipSuccess) c->abortDev = nullptr;
@@ -114,6 +122,11 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   if (rank == 0) shm_unlink(c->name);      // every rank has mapped it: the name can go now, so a rank that dies later leaks nothing in /dev/shm
   *comm = (ncclComm_t)c;
   return ncclSuccess;
+}
+ncclResult_t ncclCommInitRankConfig(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank, ncclConfig_t* config) {
+  const ncclResult_t r = ncclCommInitRank(comm, nranks, id, rank);
+  if (r == ncclSuccess && config) ((Comm*)*comm)->blocking = config->blocking != 0;
+  return r;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   Comm* c = (Comm*)comm;
@@ -130,7 +143,7 @@ ncclResult_t ncclCommAbort(ncclComm_t comm) {
 }
 ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError) {
   if (!comm || !asyncError) return ncclInvalidArgument;
-  *asyncError = ncclSuccess;
+  *asyncError = ((Comm*)comm)->inProgress ? ncclInProgress : ncclSuccess;
   return ncclSuccess;
 }
 const char* ncclGetErrorString(ncclResult_t r) {
@@ -142,8 +155,12 @@ const char* ncclGetErrorString(ncclResult_t r) {
     default: return "loopback: error";
   }
 }
-ncclResult_t ncclGroupStart() { return ncclSuccess; }      // calls run where they are made: receives never depend on this rank's sends
-ncclResult_t ncclGroupEnd() { return ncclSuccess; }
+ncclResult_t ncclGroupStart() { g_lastGrouped = nullptr; return ncclSuccess; }      // calls run where they are made: receives never depend on this rank's sends
+ncclResult_t ncclGroupEnd() {
+  Comm* c = g_lastGrouped; g_lastGrouped = nullptr;
+  if (host_stuck(c)) { c->inProgress = 1; return ncclInProgress; }      // the peer's side of the connections never comes
+  return ncclSuccess;
+}
 ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream) {
   Comm* c = (Comm*)comm;
   if (!c || !type_bytes(type) || peer < 0 || peer >= c->n || peer == c->rank) return ncclInvalidArgument;
@@ -152,6 +169,8 @@ ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t type, i
 ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream) {
   Comm* c = (Comm*)comm;
   if (!c || !type_bytes(type) || peer < 0 || peer >= c->n || peer == c->rank) return ncclInvalidArgument;
+  g_lastGrouped = c;
+  if (host_stuck(c)) return ncclSuccess;       // queued in the group; ncclGroupEnd reports the state
   if (getenv("MOPTIX_LOOPBACK_STUCK")) {      // the peer never sends: what the caller gets from RCCL then is a kernel that does not end
     if (!c->abortDev) return ncclSystemError;
     k_stuck<<<1, 64, 0, stream>>>(c->abortDev, 3000000000ull);

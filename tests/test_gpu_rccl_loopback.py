@@ -37,15 +37,20 @@ def test_n_ranks_gather_and_reduce_through_the_c_abi(n):
 
 
 @pytest.mark.gpu
-def test_a_peer_that_never_sends_ends_the_collective_at_its_deadline():
-    """moptix_gather_tiles with a peer that joined the communicator and then never calls: the receive's kernel sits on rank 0's
-    stream and does not end (MOPTIX_LOOPBACK_STUCK models RCCL's spinning kernel).  comm_wait polls the stream, aborts the
-    communicator after comm_timeout_ms (1.5 s here) and the call returns MOPTIX_ERR_COMM; the context is a one-rank context again."""
-    e = _env(); e["MOPTIX_LOOPBACK_STUCK"] = "1"; e["RCCL_TWO_RANKS_DEAD_PEER"] = "1"
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_a_peer_that_never_sends_ends_the_collective_at_its_deadline(where):
+    """moptix_gather_tiles with a peer that joined the communicator and then never calls.  "device": the receive's kernel sits on rank 0's
+    stream and does not end (MOPTIX_LOOPBACK_STUCK=1 models RCCL's spinning kernel); comm_wait polls the stream and aborts the communicator
+    after comm_timeout_ms (1.5 s here).  "host" (ADVICE r5): the call never gets that far -- the library is still setting the peer's
+    connections up, which a blocking communicator does INSIDE ncclGroupEnd; the communicator is therefore non-blocking
+    (ncclCommInitRankConfig), ncclGroupEnd returns ncclInProgress (MOPTIX_LOOPBACK_STUCK=2) and comm_settle polls the communicator's state
+    against the same deadline.  Either way the call returns MOPTIX_ERR_COMM and the context is a one-rank context again."""
+    e = _env(); e["MOPTIX_LOOPBACK_STUCK"] = "1" if where == "device" else "2"; e["RCCL_TWO_RANKS_DEAD_PEER"] = "1"
     p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "rccl_two_ranks.py"), "2", "--same-device"],
                        env=e, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
     assert "came back after" in p.stdout and "code -6" in p.stdout and "dead peer: rank 0's collective was aborted" in p.stdout, p.stdout[-1500:]
+    assert ("still in progress on the host" in p.stdout) == (where == "host"), p.stdout[-1500:]
 
 
 def _read_png(path):
@@ -78,6 +83,54 @@ def test_cli_spawn_ends_the_other_ranks_when_one_fails(tmp_path):
     e = dict(os.environ); e.pop("MOPTIX_RCCL_LIB", None)
     r = subprocess.run([exe] + args, env=e, capture_output=True, text=True, timeout=200)
     assert r.returncode != 0, r.stderr[-1000:]
+
+
+def _bench_two_ranks(e, split, extra=()):
+    sys.path.insert(0, REPO)
+    import bench
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e["MOPTIX_BENCH_BACKEND"] = "gloo"; e["MOPTIX_BENCH_DEVICE"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(bench.free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "320", "--height", "180", "--spp", "8", "--no-cpu-baseline", "--no-fast-leg", "--split", split] + list(extra)
+    return subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.gpu
+def test_bench_py_times_both_modes_in_one_run_and_reports_the_better():
+    """from PIPELINE_FROM_RANKS ranks on (8; lowered to 2 here) one run times BOTH modes -- one frame at a time, then two
+    frames in flight (second context + second communicator per rank, made when the mode starts, with its own pre-flight collective) -- K steps
+    each; config.modes carries both, `value` is the better one and config.mode names it."""
+    import json
+    e = _env(); e["MOPTIX_BENCH_PIPELINE_FROM"] = "2"; e.pop("MOPTIX_BENCH_PIPELINE", None)
+    p = _bench_two_ranks(e, "tile")
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    modes = d["config"]["modes"]
+    assert set(modes) == {"one_frame", "two_in_flight"} and all(m["ms_per_frame"] > 0 for m in modes.values())
+    assert d["config"]["mode"] == min(modes, key=lambda m: modes[m]["ms_per_frame"]) and d["ms_per_step"] == modes[d["config"]["mode"]]["ms_per_frame"]
+    assert d["config"]["pipeline"] == (d["config"]["mode"] == "two_in_flight") and d["pmc_live"] is False
+    assert "non-blocking" in d["config"]["communicator"] and d["config"]["communicator_note"] is None
+
+
+@pytest.mark.gpu
+def test_bench_py_prints_an_error_line_when_the_ranks_cannot_communicate():
+    """A peer that never delivers (MOPTIX_LOOPBACK_STUCK=1: rank 0's receive is a kernel that does not end): the pre-flight collective hits its
+    deadline (1.5 s here), every rank falls back to a blocking communicator once, that fails too, and rank 0 prints ONE JSON line with "error" and
+    each rank's diagnosis; the processes exit non-zero -- nobody hangs, nobody is re-executed."""
+    import json
+    e = _env(); e["MOPTIX_LOOPBACK_STUCK"] = "1"; e["MOPTIX_BENCH_PREFLIGHT_MS"] = "1500"
+    p = _bench_two_ranks(e, "tile")
+    assert p.returncode != 0, p.stdout[-1500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and "pre-flight" in d["error"] and d["n_gpus"] == 2
+    diag = d["config"]["ranks"]["diagnosis"]
+    assert len(diag) == 2 and "rank 0" in diag[0] and ("aborted" in diag[0] or "abandoned" in diag[0]) and diag[1].endswith("ok")
 
 
 @pytest.mark.gpu
