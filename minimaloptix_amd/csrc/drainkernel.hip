@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(64) pt_drainkernel(const LaunchArgs a) {
   SceneView scv = a.scene;
   scv.shadowNearest = NEAR ? 1 : 0;
   const SceneView& sc = scv;
-  const int nDeep = a.drainList[0], total = nDeep + a.drainList[2];
+  int* dl = a.workCounter + kDrainList;
+  const int nDeep = dl[kDrainDeepN], total = nDeep + dl[kDrainOtherN], cap = dl[kDrainCap];
   if (total == 0) return;
   const SlotCold* cold = reinterpret_cast<const SlotCold*>(a.poolCold);
   const int triBase = sc.nSpheres + sc.nQuads;
@@ -132,11 +133,11 @@ __global__ void __launch_bounds__(64) pt_drainkernel(const LaunchArgs a) {
   for (;;) {
     // ---- a lane without a path takes the next one from the list: the state run_batch (packetkernel.hip) would have loaded ----
     if (lane < kDP && ps.mode == M_DONE && !listEmpty) {
-      const int k = atomicAdd(a.drainList + 1, 1);
+      const int k = atomicAdd(dl + kDrainNext, 1);
       if (k >= total) listEmpty = true;
       else {
         // deep paths first (they are the ones that may walk to the cap: the launch ends when the last of them does)
-        const SlotCold* cs = cold + (k < nDeep ? a.drainList[4 + k] : a.drainList[4 + a.drainCap - 1 - (k - nDeep)]);
+        const SlotCold* cs = cold + (k < nDeep ? dl[kDrainEntries + k] : dl[kDrainEntries + cap - 1 - (k - nDeep)]);
         const i4 ctl = slot_load(&cs->ctl);
         const v4 thrIn = slot_load(&cs->thr), radIn = slot_load(&cs->rad);
         const v4 na = slot_load(&cs->spare[0]), nb = slot_load(&cs->spare[1]);
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(64) pt_drainkernel(const LaunchArgs a) {
 
 }  // namespace
 
-size_t drain_list_ints(int nBlocks, int drainBelow) { return 4 + (size_t)nBlocks * (size_t)(drainBelow > 0 ? drainBelow : 0); }
+size_t drain_list_ints(int nBlocks, int drainBelow) { return kDrainEntries + (size_t)nBlocks * (size_t)(drainBelow > 0 ? drainBelow : 0); }
 
 template <bool CNT, bool FAST>
 static void launch_dk(dim3 grid, hipStream_t stream, const LaunchArgs& a) {

@@ -10,7 +10,7 @@ struct LaunchArgs {
   const int* seeds; int nSeeds;     // launch seeds, one sample per pixel each (device memory)
   float* accum;                     // accuBuffer: float3 W*H, row 0 = bottom
   float* sampleBuf;                 // per-sample results: float3 [nSeeds][nItems]
-  int* workCounter;                 // [0] global work-item counter, [1] watchdog flag (both zeroed before the launch)
+  int* workCounter;                 // [0] global work-item counter, [1] watchdog flag (both zeroed before the launch); variant 4: the drain list behind them (kDrain*)
   int nItems;                       // pixels-slots of this rank = local tiles * 64
   int nWork;                        // work items = nSeeds * nItems, item k = (sample k / nItems, slot k % nItems)
   int tilesX; int rank, nRanks;     // 8x8 tile grid + tile-interleaved partition
@@ -31,18 +31,20 @@ struct LaunchArgs {
   int unitShift;                    // log2 of the slots per history unit: 6 = 8x8 tile, 0 = pixel
   const int* tileOrder;             // unit visited i-th (device, nItems >> unitShift entries) or nullptr = raster order
   unsigned int* tileCost;           // per unit: deepest path seen so far (device) or nullptr
-  // the launch's last paths (packetkernel.hip -> drainkernel.hip): a workgroup of the packet kernel that is down to drainBelow paths
-  // hands each of them over at its next packet boundary -- the slot record in poolCold is complete then -- and leaves
-  int* drainList;                   // [0] deep paths handed over (entries [4 ..] upwards), [1] the drain kernel's hand-out counter, [2] the other paths
-                                    // (entries [4 + drainCap - 1 ..] downwards); an entry = the path's slot record, as an index into poolCold
-  int drainBelow;                   // 0 = off
-  int drainCap;                     // entries the list holds: workgroups x drainBelow
 #ifdef PT_EVLOG
   unsigned long long* evLog;        // experiment build (packetkernel.hip PT_EV): [0] events so far, [1..] the events
 #endif
 };
 constexpr int kDeepPath = 8;        // paths at least this deep are recorded in tileCost
 constexpr int kDrainDeep = 24;      // paths at least this deep go to the front of the drain list
+// The launch's last paths (packetkernel.hip -> drainkernel.hip): a workgroup of the packet kernel that is down to `below` paths hands each of them
+// over at its next packet boundary -- the slot record in poolCold is complete then -- and leaves.  The list lives behind the work counter
+// (LaunchArgs::workCounter + kDrainList) and NOT in LaunchArgs: sixteen more bytes of kernel arguments moved the packet kernel's register
+// allocation and cost 0.8 % of the benchmark frame (NOTEBOOK.md round 6).
+//   [kDrainDeepN] deep paths handed over (entries upwards from kDrainEntries), [kDrainNext] the drain kernel's hand-out counter,
+//   [kDrainOtherN] the other paths (entries downwards from kDrainEntries + cap - 1), [kDrainCap] entries the list holds (workgroups x below),
+//   [kDrainBelow] the threshold (0 = off); an entry = the path's slot record, as an index into poolCold
+constexpr int kDrainList = 2, kDrainDeepN = 0, kDrainNext = 1, kDrainOtherN = 2, kDrainCap = 4, kDrainBelow = 5, kDrainEntries = 6;
 
 #if defined(__HIPCC__)
 // work item k -> (sample index, pixel).  Slot i = k % nItems is the (i & 63)-th pixel of this
@@ -107,7 +109,7 @@ size_t packetkernel_overflow_ints(int nBlocks, int ovfDepth);
 hipError_t launch_packetkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading);
 // drainkernel.hip: finishes the paths the packet kernel's workgroups handed over (LaunchArgs::drainList); same stream, right after it
 hipError_t launch_drainkernel(hipStream_t stream, const LaunchArgs& a, int nCUs, bool counted, bool fastShading);
-size_t drain_list_ints(int nBlocks, int drainBelow);
+size_t drain_list_ints(int nBlocks, int drainBelow);      // ints behind LaunchArgs::workCounter + kDrainList
 hipError_t launch_debug_trace(hipStream_t stream, const SceneView& sc, const float* dRays, int n, float* dT, int* dPrim, int* stackOverflow);
 // node steps and triangle tests of one sample per pixel of sc.width x sc.height, paths cut at depth 6, under one node format
 // (dOut[0..1] += ; megakernel.hip k_probe_paths)

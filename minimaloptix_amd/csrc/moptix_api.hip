@@ -96,7 +96,7 @@ struct moptix_context_t {
   DevBuf<TriUV> dFaceUV; DevBuf<float> dTexels; DevBuf<DevTexture> dTextures;
   LbvhResult bvh;
   DevBuf<float> dAccum; float* accumBound = nullptr; size_t accumPixels = 0;
-  DevBuf<int> dSeeds; DevBuf<int> dWork; DevBuf<unsigned long long> dCounters; DevBuf<int> dOverflow; DevBuf<int> dDrainList; DevBuf<uint8_t> dRgb8;
+  DevBuf<int> dSeeds; DevBuf<int> dWork; DevBuf<unsigned long long> dCounters; DevBuf<int> dOverflow; DevBuf<uint8_t> dRgb8;
   DevBuf<uint8_t> dPoolCold; DevBuf<float> dSampleBuf;
 
   int rank = 0, nRanks = 1;
@@ -360,6 +360,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   a.slotsInUse = c->optSlotsInUse >= 0 ? c->optSlotsInUse : (usePacket && c->optAuxDepth > 0 && nSamples < 1.0e8 && c->glassFaceShare <= 0.5 ? packetkernel_slots() * 7 / 8 : 0);
   a.auxDepth = usePacket ? c->optAuxDepth : 0;
   a.watchdogTicks = (unsigned long long)c->optWatchdogMs * 100000ull;      // s_memrealtime counts at 100 MHz
+  int drainBelow = 0;      // variant 4: the packet kernel's workgroups hand their last paths to the drain kernel (drainkernel.hip)
   if (usePacket) {
     a.ovfDepth = std::max(0, c->bvh.stackBound - packetkernel_lds_stack_entries() + 1);
     if (a.ovfDepth > 0) {
@@ -373,11 +374,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     // traversal order, and the drain kernel's order is not the packet kernel's)
     bool glassMaterial = false;
     for (const DevMaterial& m : c->mats) if (m.kind == MAT_DISNEY && m.brdfType == BRDF_GLASS) glassMaterial = true;
-    a.drainBelow = (glassMaterial && !a.scene.shadowNearest) ? 0 : c->optDrainBelow;
-    if (a.drainBelow > 0) {
-      HIPCHK(c, c->dDrainList.ensure(drain_list_ints(nBlocks, a.drainBelow)), "alloc drain list");
-      a.drainList = c->dDrainList.p; a.drainCap = nBlocks * a.drainBelow;
-    }
+    drainBelow = (glassMaterial && !a.scene.shadowNearest) ? 0 : c->optDrainBelow;
   } else if (useQueue && leanQueue) {
     // no tree to walk (queuekernel_lean.hip): a fourth workgroup per CU instead of path slots and stack entries
     if (c->optBlocksPerCU == 3) nBlocks = c->numCUs * 4;
@@ -410,7 +407,13 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
     perPass = (perPass + 1) / 2;
   }
   a.sampleBuf = c->dSampleBuf.p;
-  HIPCHK(c, c->dWork.ensure(2), "alloc work counter");   // [0] work counter, [1] watchdog flag
+  // [0] work counter, [1] watchdog flag, then (variant 4) the drain list (megakernel.h kDrain*): counters, capacity, threshold, entries
+  HIPCHK(c, c->dWork.ensure(2 + drain_list_ints(nBlocks, drainBelow)), "alloc work counter");
+  {
+    const int hdr[2 + kDrainEntries] = { 0, 0, 0, 0, 0, 0, nBlocks * drainBelow, drainBelow };
+    HIPCHK(c, hipMemcpyAsync(c->dWork.p, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream), "init work counter");
+    HIPCHK(c, hipStreamSynchronize(c->stream), "sync");      // hdr lives on this stack frame
+  }
   a.tileMajor = (useQueue || usePacket) ? c->optTileMajor : 0;
   a.tileOrder = nullptr; a.tileCost = nullptr;
   a.unitShift = a.tileMajor == 3 ? 0 : 6;
@@ -452,7 +455,7 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
   for (long long first = 0; first < nSeeds; first += perPass) {
     const int n = (int)std::min(perPass, (long long)nSeeds - first);
     a.seeds = c->dSeeds.p + first; a.nSeeds = n; a.nWork = n * a.nItems;
-    HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, 2 * sizeof(int), c->stream), "zero work counter");
+    HIPCHK(c, hipMemsetAsync(c->dWork.p, 0, (2 + kDrainCap) * sizeof(int), c->stream), "zero work counter");      // counters only: capacity and threshold stay
     if (a.tileMajor && a.tileCost) {
       // tiles in descending order of the deepest path seen so far (stable: ties stay in raster order)
       size_t tmpBytes = c->dSortTmp.n;
@@ -460,9 +463,8 @@ int do_render(moptix_context c, const int32_t* seeds, int32_t nSeeds, bool count
                                                (size_t)historyUnits, 0, 32, c->stream), "sort tiles");
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream), "event");
-    if (usePacket && a.drainBelow > 0) HIPCHK(c, hipMemsetAsync(a.drainList, 0, 4 * sizeof(int), c->stream), "zero drain list");
     if (usePacket) HIPCHK(c, launch_packetkernel(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch packet megakernel");
-    if (usePacket && a.drainBelow > 0) HIPCHK(c, launch_drainkernel(c->stream, a, c->numCUs, counted, c->optFastShading != 0), "launch drain kernel");
+    if (usePacket && drainBelow > 0) HIPCHK(c, launch_drainkernel(c->stream, a, c->numCUs, counted, c->optFastShading != 0), "launch drain kernel");
     else if (useQueue && leanQueue) HIPCHK(c, launch_queuekernel_lean(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch queue megakernel (lean)");
     else if (useQueue) HIPCHK(c, launch_queuekernel(c->stream, a, nBlocks, counted, c->optFastShading != 0), "launch queue megakernel");
     else HIPCHK(c, launch_megakernel(c->stream, a, nBlocks, counted), "launch megakernel");
@@ -694,7 +696,7 @@ int moptix_destroy(moptix_context c) {
   lbvh_free(&c->bvh);
   c->dPoolCold.release(); c->dSampleBuf.release();
   c->dTileCost.release(); c->dTileCostSorted.release(); c->dTileOrder.release(); c->dTileIota.release(); c->dSortTmp.release();
-  c->dAccum.release(); c->dSeeds.release(); c->dWork.release(); c->dCounters.release(); c->dOverflow.release(); c->dDrainList.release(); c->dRgb8.release();
+  c->dAccum.release(); c->dSeeds.release(); c->dWork.release(); c->dCounters.release(); c->dOverflow.release(); c->dRgb8.release();
   c->dTileSend.release(); c->dTileRecv.release();
   if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
   if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -81,6 +81,7 @@ struct PoolLds {
   unsigned short queue[kNumQ][ring_capacity(NS)];
   int qHead[kNumQ], qCount[kNumQ];   // SHARED only
   int done, lock;                    // SHARED only
+  int drainAt;                       // once this many slots are done the pool stops shading and hands its last paths to the drain kernel (set at start-up)
   // Concurrent shadow rays for deep paths (LaunchArgs::auxDepth): a slot whose path is done (the work items ran out, or
   // LaunchArgs::slotsInUse left it without one) can be borrowed by a deep path, one per shadow ray of a hit, so that
   // the shadow rays and the continuation are traced at the same time: the launch's tail is a few capped paths walking
@@ -299,7 +300,8 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     if constexpr (SHARED) {
       if (threadIdx.x == 0) {
         for (int q = 0; q < kNumQ; q++) { W.qHead[q] = 0; W.qCount[q] = 0; }
-        W.qCount[Q_GEN] = nUse; W.done = NS - nUse; W.lock = 0;
+        W.qCount[Q_GEN] = nUse; const int below = a.workCounter[kDrainList + kDrainBelow];
+        W.done = NS - nUse; W.drainAt = below > 0 ? max(0, NS - below) : 0x7fff; W.lock = 0;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
@@ -670,49 +672,6 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     PT_EV(4, __popcll(__ballot(useAux)));
   };
 
-  // ---- hand-over (LaunchArgs::drainBelow): the popped slots' paths go on in the drain kernel ----
-  // Once a workgroup is down to a few paths -- the launch's drain: paths walking to the depth cap, one dependent pass after the other through
-  // this scheduler, 36 us per bounce in an idle machine (profiles/r06_tail_anatomy.txt) -- every path that comes back from its packet is
-  // handed over instead of shaded: the slot record already holds the path (ctl thr rad hit bsc pend att), the 36 bytes that live in LDS go
-  // into its two spare rows, and a borrowed slot's verdict is copied to where an unborrowed packet would have left it.  The workgroup leaves
-  // when its last path has been handed over; drainkernel.hip walks those paths with a wave each.
-  auto hand_over = [&](int slot) {
-    const LaunchArgs& a = fresh_args();
-    pendSlot = slot; pendDest = DEST_NONE;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (slot >= 0) {
-      SlotCold* cw = at32(cold, slot);
-      int fl = W.stack[slot][0];
-      const i4 ctl = slot_load(&cw->ctl);
-      if ((ctl.w & 7) == M_TRACE) {                     // a traced packet (anything else in these queues only waits for a work item, and there is none)
-        if (fl & kHasAux) {
-          const int axp = f2i(slot_load(&cw->thr).w);
-          const int nSh = (fl >> kPendShift) & 3;
-#pragma unroll
-          for (int i = 0; i < kPacketShadows; i++) {
-            if (i < nSh) {
-              const int ax = (axp >> (kSlotBits * i)) & kSlotMask;
-              const int stt = fl_stat(W.stack[ax][0], 0);
-              fl = (fl & ~(3 << (kStatShift + 2 * i))) | (stt << (kStatShift + 2 * i));
-              if (stt == 2) slot_store(&cw->att[i], slot_load(&at32(cold, ax)->att[0]));
-            }
-          }
-          fl &= ~(kHasAux | kJoinMask);
-        }
-        const v4 na = W.nodeA[slot], nb = W.nodeB[slot];
-        slot_store(&cw->spare[0], na);
-        slot_store(&cw->spare[1], mk4(nb.x, nb.y, nb.z, i2f(fl)));
-        // the list has two ends: deep paths from the front, the others from the back (the drain kernel starts with the deep ones)
-        const bool deep = ctl.y >= kDrainDeep;
-        const int idx = atomicAdd(a.drainList + (deep ? 0 : 2), 1);
-        a.drainList[deep ? 4 + idx : 4 + a.drainCap - 1 - idx] = gpool * NS + slot;
-      }
-      W.stack[slot][0] = 0;
-      pendDest = DEST_DONE;
-    }
-  };
-
   unsigned int guard = 0;
   const unsigned long long wdStart = __builtin_amdgcn_s_memrealtime();
   for (;;) {
@@ -787,21 +746,23 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         qCount[q] += obCount[d]; obCount[d] = 0;
       }
       nDone += localDone; localDone = 0;
-      // the workgroup is down to its last paths: whatever comes back from its packet is handed to the drain kernel (hand_over)
-#ifndef PT_HANDOVER
-#define PT_HANDOVER 1
-#endif
-      if (PT_HANDOVER && a.drainBelow > 0 && NS - nDone <= a.drainBelow && qCount[Q_SHADE] + qCount[Q_GEN] > 0) pass = 5;
-      else if (qCount[Q_SHADE] >= 64) pass = 1;
+      if (qCount[Q_SHADE] >= 64) pass = 1;
       else if (qCount[Q_GEN] >= 64) pass = 2;
       else if (lqCount >= 64) pass = 0;
       else if (starving) {
-        const int l = lqCount, sh = qCount[Q_SHADE], g = qCount[Q_GEN];
-        if (l + sh + g == 0) { if (nActive == 0) pass = (nDone == NS) ? 4 : 3; }
-        else pass = (l >= sh && l >= g) ? 0 : (sh >= g ? 1 : 2);
+        const int l = lqCount;
+        int sh = qCount[Q_SHADE], g = qCount[Q_GEN];
+        // The pool is down to its last paths (LaunchArgs drain list, megakernel.h): no more partial shading batches.  Rays in flight are
+        // walked to the end of their packets; once every path that is left waits in one of the two queues the workgroup leaves the loop and
+        // hands them to the drain kernel (after the loop: hand-over).  Only this branch knows about it -- the pass selection of a full pool
+        // is what it was.
+        if (nDone >= W.drainAt) { if (nDone + sh + g == NS && nActive == 0 && l == 0) pass = 4; sh = 0; g = 0; }
+        if (pass != 4) {
+          if (l + sh + g == 0) { if (nActive == 0) pass = (nDone == NS) ? 4 : 3; }
+          else pass = (l >= sh && l >= g) ? 0 : (sh >= g ? 1 : 2);
+        }
       }
       if (pass == 1 || pass == 2) mySlot = q_pop(pass == 1 ? Q_SHADE : Q_GEN, true);
-      else if (pass == 5) mySlot = q_pop(qCount[Q_SHADE] > 0 ? Q_SHADE : Q_GEN, true);
       txn_end();
       if (pass == 0) mySlot = leaf_pop();
       PT_EV(10, pass + 1);
@@ -811,7 +772,6 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
     PT_STAMP(tSwap);
     if (pass == 4) break;
     if (pass == 3) { if (CNT) idleSpins++; __builtin_amdgcn_s_sleep(32); PT_SUB(tIdle); PT_STAMP(tSwap); continue; }
-    if (pass == 5) { hand_over(mySlot); PT_STAMP(tBatch); continue; }
     if (pass == 0) { leaf_pass(mySlot); PT_STAMP(tLeaf); continue; }
     if (pass > 0) { run_batch(mySlot, pass == 1); PT_STAMP(tBatch); continue; }
 
@@ -839,6 +799,56 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
 #endif
     }
     PT_STAMP(tNode);
+  }
+
+  // ---- hand-over: the paths that are left go on in the drain kernel (drainkernel.hip) ----
+  // The launch's drain is a few paths walking to the depth cap, one dependent pass after the other through this scheduler: 36 us per bounce
+  // in an idle machine (profiles/r06_tail_anatomy.txt).  A workgroup that is down to LaunchArgs' drain threshold has stopped shading
+  // (transaction above); every path it still holds has come back from its packet and sits in Q_SHADE or Q_GEN.  Its slot record already
+  // holds the path (ctl thr rad hit bsc pend att); the 36 bytes that live in LDS go into the record's two spare rows, a borrowed slot's
+  // verdict is copied to where an unborrowed packet would have left it, and the record's index goes on the drain list.  Outside the loop
+  // on purpose: inside, as one more pass, the same code cost the benchmark frame 1 % through the loop's register allocation.
+  if constexpr (SHARED) {
+    __syncthreads();
+    // (everything this block needs is taken afresh from the arguments: nothing stays live through the loop for its sake)
+    const LaunchArgs& a = fresh_args();
+    SlotCold* cold = reinterpret_cast<SlotCold*>(a.poolCold) + (size_t)blockIdx.x * NS;
+    const int gpool = blockIdx.x;
+    PoolLds<NS>& W = sPool[0];
+    if (W.done != NS && __hip_atomic_load(a.workCounter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {      // (not after the watchdog: the queues are in no defined state then)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int nSh = W.qCount[Q_SHADE], nGe = W.qCount[Q_GEN];
+      for (int e = threadIdx.x; e < nSh + nGe; e += kBlockThreads) {
+        const int q = e < nSh ? Q_SHADE : Q_GEN, r = e < nSh ? e : e - nSh;
+        const int slot = W.queue[q][ring_wrap<NS>(W.qHead[q] + r)];
+        SlotCold* cw = at32(cold, slot);
+        int fl = W.stack[slot][0];
+        const i4 ctl = slot_load(&cw->ctl);
+        if ((ctl.w & 7) != M_TRACE) continue;           // a slot that only waits for a work item (there is none)
+        if (fl & kHasAux) {
+          const int axp = f2i(slot_load(&cw->thr).w);
+          const int nS = (fl >> kPendShift) & 3;
+#pragma unroll
+          for (int i = 0; i < kPacketShadows; i++) {
+            if (i < nS) {
+              const int ax = (axp >> (kSlotBits * i)) & kSlotMask;
+              const int stt = fl_stat(W.stack[ax][0], 0);
+              fl = (fl & ~(3 << (kStatShift + 2 * i))) | (stt << (kStatShift + 2 * i));
+              if (stt == 2) slot_store(&cw->att[i], slot_load(&at32(cold, ax)->att[0]));
+            }
+          }
+          fl &= ~(kHasAux | kJoinMask);
+        }
+        const v4 na = W.nodeA[slot], nb = W.nodeB[slot];
+        slot_store(&cw->spare[0], na);
+        slot_store(&cw->spare[1], mk4(nb.x, nb.y, nb.z, i2f(fl)));
+        // the list has two ends: deep paths from the front, the others from the back (the drain kernel starts with the deep ones)
+        const bool deep = ctl.y >= kDrainDeep;
+        int* dl = a.workCounter + kDrainList;
+        const int idx = atomicAdd(dl + (deep ? kDrainDeepN : kDrainOtherN), 1);
+        dl[deep ? kDrainEntries + idx : kDrainEntries + dl[kDrainCap] - 1 - idx] = gpool * NS + slot;
+      }
+    }
   }
 
   if constexpr (CNT) {

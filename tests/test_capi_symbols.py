@@ -64,13 +64,32 @@ def test_trace_kernel_resources_are_pinned():
     assert len(bench) == 1, sorted(res)[:5]
     r = bench[0]
     assert r["vgpr_count"] <= 168, r                       # three workgroups of four waves per CU
-    # pinned at today's numbers (round 5: 2 vector, 57 scalar; round 3: 11 / 111): an edit that moves them has to say so here and in
-    # profiles/r05_kernel_resources.txt, where the numbers are kept per round
-    assert r["vgpr_spill_count"] <= 2, r
-    assert r["sgpr_spill_count"] <= 57, r
+    # pinned at today's numbers (round 6: 6 vector, 53 scalar -- the hand-over block behind the main loop moved four more vector registers
+    # to scratch and four scalar ones back, measured at the same frame time as round 5's 2 / 57; round 3: 11 / 111): an edit that moves them
+    # has to say so here and in profiles/r06_kernel_resources.txt, where the numbers are kept per round
+    assert r["vgpr_spill_count"] <= 6, r
+    assert r["sgpr_spill_count"] <= 53, r
     # LDS: three workgroups per CU.  The CU hands LDS out in blocks of 1,280 bytes: 42 blocks = 53,760 bytes each (54,128 bytes ran two
     # workgroups per CU in round 4 -- frame 105 instead of 79 ms -- although hipOccupancyMaxActiveBlocksPerMultiprocessor says 3 up to 54,592)
     assert r["group_segment_fixed_size"] <= 53760, r
     for k, v in res.items():                               # every variant of the packet kernel keeps three workgroups per CU
         if "pt_packetkernel" in k:
             assert v["vgpr_count"] <= 168 and v["group_segment_fixed_size"] <= 53760, (k, v)
+
+
+def test_queue_and_drain_kernel_resources_are_pinned():
+    """pt_queuekernel (variant 3: random_spheres' kernel and the fall-back for scenes outside the packet kernel's limits)
+    ships with spilled registers nobody looked at -- pinned here at today's numbers so that at least a regression shows.  The drain kernel
+    (csrc/drainkernel.hip) runs one wave per workgroup, eight per CU: it must stay under 256 registers (two waves per SIMD) without spills."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from kernel_resources import kernel_resources
+    res = kernel_resources(os.path.join(REPO, "minimaloptix_amd", "lib", "libmoptix.so"))
+    queue = {k: v for k, v in res.items() if "pt_queuekernelILb0E" in k}        # the uncounted instantiations
+    assert len(queue) >= 4, sorted(res)[:5]
+    for k, v in queue.items():
+        assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= 40 and v["sgpr_spill_count"] <= 120, (k, v)
+    drain = {k: v for k, v in res.items() if "pt_drainkernelILb0E" in k}
+    assert len(drain) == 8, sorted(res)[:5]
+    for k, v in drain.items():
+        assert v["vgpr_count"] <= 256 and v["vgpr_spill_count"] == 0 and v["group_segment_fixed_size"] <= 20480, (k, v)
