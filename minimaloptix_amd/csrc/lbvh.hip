@@ -81,7 +81,10 @@ __global__ void k_morton(int n, const float* __restrict__ lo, const float* __res
   const v3 chi = mk3(ordered_to_float(box->cHi[0]), ordered_to_float(box->cHi[1]), ordered_to_float(box->cHi[2]));
   const v3 invExt = mk3(inv_extent(clo.x, chi.x), inv_extent(clo.y, chi.y), inv_extent(clo.z, chi.z));
   const v3 c = (mk3(lo[3 * f], lo[3 * f + 1], lo[3 * f + 2]) + mk3(hi[3 * f], hi[3 * f + 1], hi[3 * f + 2])) * 0.5f;
-  keys[f] = morton_key(c, clo, invExt, lbvh_bits_per_axis(n), lbvh_index_bits(n), f);
+  const v3 l = mk3(lo[3 * f], lo[3 * f + 1], lo[3 * f + 2]), h = mk3(hi[3 * f], hi[3 * f + 1], hi[3 * f + 2]);
+  const v3 slo = mk3(ordered_to_float(box->sLo[0]), ordered_to_float(box->sLo[1]), ordered_to_float(box->sLo[2]));
+  const v3 shi = mk3(ordered_to_float(box->sHi[0]), ordered_to_float(box->sHi[1]), ordered_to_float(box->sHi[2]));
+  keys[f] = morton_key(c, clo, invExt, lbvh_bits_per_axis(n), lbvh_index_bits(n), f) | (tri_is_big(l, h, slo, shi) ? 0ull : kSmallKeyBit);      // large triangles first (pt_lbvh.h)
 }
 
 // 3. records + padded leaf boxes in sorted order
@@ -124,7 +127,7 @@ __global__ void k_karras(int n, const uint64_t* __restrict__ keys, int* __restri
 }
 
 // 4'. binned-SAH topology (pt_lbvh.h), one workgroup per node of the current level
-struct SahTask { int node, first, count; float cbLo[3], cbHi[3]; };
+struct SahTask { int node, first, count; float cbLo[3], cbHi[3]; int force; };      // force > 0: split the range at this index (the root: large triangles | the others)
 constexpr int kWideTasks = 1024;      // the per-triangle form of a level handles at most this many nodes ...
 constexpr int kWideCount = 2048;      // ... while some node still holds more triangles than this
 constexpr int kCbReplicas = 32;       // replicas of the children's centroid boxes (see kReplicas)
@@ -133,7 +136,7 @@ __global__ void k_sah_init(int n, const uint64_t* __restrict__ keys, int* __rest
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) order[k] = key_face(keys[k], lbvh_index_bits(n));
   if (k == 0) {
-    SahTask t; t.node = 0; t.first = 0; t.count = n;
+    SahTask t; t.node = 0; t.first = 0; t.count = n; t.force = big_key_count(keys, n);
     for (int a = 0; a < 3; a++) { t.cbLo[a] = ordered_to_float(box->cLo[a]); t.cbHi[a] = ordered_to_float(box->cHi[a]); }
     *task0 = t;
   }
@@ -153,7 +156,7 @@ __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float base[3] = { t.cbLo[0], t.cbLo[1], t.cbLo[2] };
   const float scale[3] = { sah_scale(t.cbLo[0], t.cbHi[0]), sah_scale(t.cbLo[1], t.cbHi[1]), sah_scale(t.cbLo[2], t.cbHi[2]) };
-  const bool binned = useSah && t.count > leafSize;
+  const bool binned = useSah && t.count > leafSize && t.force == 0;
   if (binned) {
     for (int i = tid; i < 3 * kSahBins; i += kSahBlock) {
       const int a = i / kSahBins, b = i % kSahBins;
@@ -162,7 +165,7 @@ __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restri
     }
   }
   if (tid < 12) sCb[tid / 6][(tid / 3) & 1][tid % 3] = float_to_ordered(((tid / 3) & 1) ? -1e37f : 1e37f);
-  if (tid == 0) { sBase[0] = 0; sBase[1] = 0; sSplit.axis = -1; sSplit.bin = 0; sSplit.nLeft = (t.count + 1) / 2; }
+  if (tid == 0) { sBase[0] = 0; sBase[1] = 0; sSplit.axis = -1; sSplit.bin = 0; sSplit.nLeft = t.force > 0 ? t.force : (t.count + 1) / 2; }
   __syncthreads();
   if (binned) {
     for (int i = tid; i < t.count; i += kSahBlock) {
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(kSahBlock) k_sah_level(const SahTask* __restri
   if (tid == 0) {
     first[t.node] = t.first; last[t.node] = t.first + t.count - 1;
     for (int s2 = 0; s2 < 2; s2++) {
-      SahTask ch; ch.node = -1; ch.first = t.first + (s2 ? sp.nLeft : 0); ch.count = s2 ? t.count - sp.nLeft : sp.nLeft;
+      SahTask ch; ch.node = -1; ch.force = 0; ch.first = t.first + (s2 ? sp.nLeft : 0); ch.count = s2 ? t.count - sp.nLeft : sp.nLeft;
       for (int a = 0; a < 3; a++) { ch.cbLo[a] = ordered_to_float(sCb[s2][0][a]); ch.cbHi[a] = ordered_to_float(sCb[s2][1][a]); }
       children[2 * (size_t)blockIdx.x + s2] = ch;
     }
@@ -289,8 +292,8 @@ __global__ void k_sahw_choose(const SahTask* __restrict__ tasks, int nTasks, int
   const int ti = blockIdx.x * blockDim.x + threadIdx.x;
   if (ti >= nTasks) return;
   const SahTask t = tasks[ti];
-  SahSplit sp; sp.axis = -1; sp.bin = 0; sp.nLeft = (t.count + 1) / 2;
-  if (useSah && t.count > leafSize) sp = sah_choose(bins[ti], mk3(t.cbLo[0], t.cbLo[1], t.cbLo[2]), mk3(t.cbHi[0], t.cbHi[1], t.cbHi[2]), t.count);
+  SahSplit sp; sp.axis = -1; sp.bin = 0; sp.nLeft = t.force > 0 ? t.force : (t.count + 1) / 2;
+  if (useSah && t.count > leafSize && t.force == 0) sp = sah_choose(bins[ti], mk3(t.cbLo[0], t.cbLo[1], t.cbLo[2]), mk3(t.cbHi[0], t.cbHi[1], t.cbHi[2]), t.count);
   splits[ti] = sp;
 }
 __device__ __forceinline__ bool sahw_left(const SahTask& t, const SahSplit& sp, int p, int f, const float* __restrict__ lo, const float* __restrict__ hi) {
@@ -352,7 +355,7 @@ __global__ void k_sahw_commit(int n, const SahTask* __restrict__ tasks, int nTas
     const SahSplit sp = splits[p];
     first[t.node] = t.first; last[t.node] = t.first + t.count - 1;
     for (int s2 = 0; s2 < 2; s2++) {
-      SahTask ch; ch.node = -1; ch.first = t.first + (s2 ? sp.nLeft : 0); ch.count = s2 ? t.count - sp.nLeft : sp.nLeft;
+      SahTask ch; ch.node = -1; ch.force = 0; ch.first = t.first + (s2 ? sp.nLeft : 0); ch.count = s2 ? t.count - sp.nLeft : sp.nLeft;
       for (int a = 0; a < 3; a++) { ch.cbLo[a] = ordered_to_float(childCb[12 * (size_t)p + 6 * s2 + a]); ch.cbHi[a] = ordered_to_float(childCb[12 * (size_t)p + 6 * s2 + 3 + a]); }
       children[2 * (size_t)p + s2] = ch;
     }

@@ -23,7 +23,7 @@ namespace pt {
 // Keys are code << idxBits | face: the face index makes them unique, and all bits it does not need go to
 // the Morton code (3 x bitsPerAxis): 168 k triangles -> 18 index bits -> 15 bits (32768 cells) per axis.
 PT_HD int lbvh_index_bits(int n) { int b = 1; while ((1ll << b) < (long long)n) b++; return b; }
-PT_HD int lbvh_bits_per_axis(int n) { const int b = (64 - lbvh_index_bits(n)) / 3; return b > 21 ? 21 : b; }
+PT_HD int lbvh_bits_per_axis(int n) { const int b = (63 - lbvh_index_bits(n)) / 3; return b > 21 ? 21 : b; }      // bit 63 is kSmallKeyBit
 PT_HD uint64_t expand_bits21(uint64_t v) {
   v &= 0x1fffffull;
   v = (v | (v << 32)) & 0x001f00000000ffffull;
@@ -32,6 +32,25 @@ PT_HD uint64_t expand_bits21(uint64_t v) {
   v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
   v = (v | (v << 2)) & 0x1249249249249249ull;
   return v;
+}
+// Large triangles first (round 6).  A room's walls and floor are a dozen triangles whose boxes span the scene; binned by centroid among a
+// million small ones they stay inside subtrees of small geometry for many levels and inflate every box above them, and most rays of an
+// interior view end on exactly those triangles.  So a triangle whose box has at least kBigTriShare of the scene box's surface area sorts in
+// FRONT of all others (the others carry kSmallKeyBit) and the root's range is split between the two groups (SahTask::force; the Morton radix
+// tree of builder 0 splits there by itself: it is the keys' highest bit).  Dining-room stand-in: 4.90 -> 2.64 node steps per ray on the
+// per-lane walk, the exact-sweep SAH gives 2.90 (tools/tree_yardstick.py, profiles/r06_tree_yardstick.txt); scenes without such triangles:
+// the same tree as before.
+constexpr uint64_t kSmallKeyBit = 1ull << 63;
+constexpr float kBigTriShare = 1.0f / 64.0f;
+PT_HD bool tri_is_big(v3 lo, v3 hi, v3 slo, v3 shi) {
+  const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z, sx = shi.x - slo.x, sy = shi.y - slo.y, sz = shi.z - slo.z;
+  return (dx * dy + dy * dz) + dz * dx >= kBigTriShare * ((sx * sy + sy * sz) + sz * sx);
+}
+// number of keys in front of the first small one (sorted keys): the forced split of the root's range, 0 = none
+PT_HD int big_key_count(const uint64_t* keys, int n) {
+  int a = 0, b = n;
+  while (a < b) { const int m = (a + b) >> 1; if (keys[m] & kSmallKeyBit) b = m; else a = m + 1; }
+  return (a > 0 && a < n) ? a : 0;
 }
 PT_HD uint64_t morton_key(v3 p, v3 lo, v3 invExt, int bitsPerAxis, int idxBits, int face) {
   const v3 n = (p - lo) * invExt;

@@ -350,3 +350,52 @@ light
     with open(os.path.join(d, "cornell.scene"), "w") as f:
         f.write(scene)
     return str(root) + "/"
+
+
+def tree_containment_errors(nodes, tris, root, nodes64=None):
+    """is this tree VALID?  Every child box of every node (the 128-byte form, and the decoded 64-byte form when given) must
+    contain the bounds of all triangles below that child; a builder bug -- a child box that fails to enclose its triangles under some
+    leaf size / builder / Node64 rounding -- would make every kernel miss the same triangle, and a comparison of kernels on that tree
+    could not see it.  nodes: [n, 32] words (pt_types.h Node128), tris: [m, 12] words (Tri48: p0 mat e0 prim e1 shadow), root: node
+    index or leaf reference.  Returns the number of (node, child) pairs whose box does not contain its triangles."""
+    nodes = np.ascontiguousarray(nodes, np.uint32); tris = np.ascontiguousarray(tris, np.uint32)
+    f = tris.view(np.float32)
+    p0 = f[:, 0:3].astype(np.float64); p1 = p0 + f[:, 4:7]; p2 = p0 - f[:, 8:11]       # e0 = p1 - p0, e1 = p0 - p2 (rounded once: compare with slack)
+    tlo = np.minimum(np.minimum(p0, p1), p2); thi = np.maximum(np.maximum(p0, p1), p2)
+    nf = nodes.view(np.float32)
+    box128 = nf[:, 0:24].reshape(-1, 6, 4)                                              # lox loy loz hix hiy hiz x child
+    refs = nodes[:, 24:28].view(np.int32); count = nodes[:, 28].view(np.int32)
+    box64 = node64_boxes(nodes64)[0] if nodes64 is not None else None
+    bad = 0
+    if root < 0:
+        return 0
+    # post-order over the tree: exact bounds of every subtree
+    lo = {}; hi = {}
+    stack = [(int(root), False)]
+    while stack:
+        n, done = stack.pop()
+        if not done:
+            stack.append((n, True))
+            for k in range(int(count[n])):
+                r = int(refs[n, k])
+                if r >= 0:
+                    stack.append((r, False))
+            continue
+        nlo = np.full(3, np.inf); nhi = np.full(3, -np.inf)
+        for k in range(int(count[n])):
+            r = int(refs[n, k])
+            if r >= 0:
+                clo, chi = lo[r], hi[r]
+            else:
+                first, cnt = (~r) >> 3, ((~r) & 7) + 1
+                clo, chi = tlo[first:first + cnt].min(axis=0), thi[first:first + cnt].max(axis=0)
+            eps = 1e-6 * np.maximum(1.0, np.abs(chi) + np.abs(clo))                     # p1 / p2 are reconstructed from rounded edges
+            for boxes in (box128, box64):
+                if boxes is None:
+                    continue
+                b = boxes[n, :, k].astype(np.float64)
+                if (b[0:3] > clo + eps).any() or (b[3:6] < chi - eps).any():
+                    bad += 1
+            nlo = np.minimum(nlo, clo); nhi = np.maximum(nhi, chi)
+        lo[n], hi[n] = nlo, nhi
+    return bad

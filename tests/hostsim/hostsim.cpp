@@ -71,6 +71,7 @@ static int subtree_depth(const std::vector<Node128>& nodes, int ref) {
 // Host mirror of the device's binned-SAH topology (lbvh.hip k_sah_level / k_sah_finalize; shared functions and the
 // definition of the algorithm: pt_lbvh.h).  order: Morton order on entry, final order on return; nodes: n-1 entries.
 struct SahTask { int node, first, count; v3 cbLo, cbHi; };
+static int g_forcedRootSplit = 0;     // device: SahTask::force of the root task
 static void build_sah_topology(const std::vector<v3>& lo, const std::vector<v3>& hi, std::vector<int>& order, v3 cbLo, v3 cbHi,
                                int leafSize, std::vector<KarrasNode>& nodes, std::vector<int>& parentI, std::vector<int>& parentL) {
   const int n = (int)order.size();
@@ -84,10 +85,47 @@ static void build_sah_topology(const std::vector<v3>& lo, const std::vector<v3>&
     const int nextBase = idBase + (int)tasks.size();
     for (const SahTask& t : tasks) {
       SahSplit sp; sp.axis = -1; sp.bin = 0; sp.nLeft = (t.count + 1) / 2;
+      // HOSTSIM_SWEEP=1 -- a YARDSTICK, not the device's builder: the exact surface-area heuristic, every one of the
+      // 3 x (count - 1) object splits of the range sorted by centroid evaluated, instead of the 3 x (kSahBins - 1) planes of the binned form.
+      // HOSTSIM_SWEEP=2 adds the leaf-cost term (a split is taken only if cheaper than the range as one leaf is NOT used here: the array
+      // form needs the full topology, and leaves are collapsed by size afterwards as on the device).
+      static const int sweepMode = getenv("HOSTSIM_SWEEP") ? atoi(getenv("HOSTSIM_SWEEP")) : 0;
+      const bool forced = level == 0 && g_forcedRootSplit > 0;
+      if (forced) { sp.axis = -1; sp.nLeft = g_forcedRootSplit; }
+      const bool swept = !forced && sweepMode && t.count > leafSize && level < kSahLevels;
+      if (swept) {
+        float bestCost = 3.0e38f; int bestAxis = -1, bestK = 0;
+        std::vector<int> idx(t.count), bestOrder;
+        std::vector<float> ra(t.count);
+        for (int a = 0; a < 3; a++) {
+          for (int i = 0; i < t.count; i++) idx[i] = order[t.first + i];
+          auto cenA = [&](int f) { const v3 c = (lo[f] + hi[f]) * 0.5f; return a == 0 ? c.x : a == 1 ? c.y : c.z; };
+          std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return cenA(x) < cenA(y); });
+          v3 bl = mk3(1e37f, 1e37f, 1e37f), bh = mk3(-1e37f, -1e37f, -1e37f);
+          auto area = [](v3 l, v3 h) { const float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z; return dx * dy + dy * dz + dz * dx; };
+          for (int i = t.count - 1; i >= 1; i--) {
+            const int f = idx[i];
+            bl = mk3(fminf_(bl.x, lo[f].x), fminf_(bl.y, lo[f].y), fminf_(bl.z, lo[f].z)); bh = mk3(fmaxf_(bh.x, hi[f].x), fmaxf_(bh.y, hi[f].y), fmaxf_(bh.z, hi[f].z));
+            ra[i] = area(bl, bh);
+          }
+          bl = mk3(1e37f, 1e37f, 1e37f); bh = mk3(-1e37f, -1e37f, -1e37f);
+          for (int k = 1; k < t.count; k++) {           // left = idx[0 .. k-1]
+            const int f = idx[k - 1];
+            bl = mk3(fminf_(bl.x, lo[f].x), fminf_(bl.y, lo[f].y), fminf_(bl.z, lo[f].z)); bh = mk3(fmaxf_(bh.x, hi[f].x), fmaxf_(bh.y, hi[f].y), fmaxf_(bh.z, hi[f].z));
+            const float cost = area(bl, bh) * (float)k + ra[k] * (float)(t.count - k);
+            if (cost < bestCost) { bestCost = cost; bestAxis = a; bestK = k; }
+          }
+          if (bestAxis == a) bestOrder = idx;
+        }
+        if (bestAxis >= 0) {
+          for (int i = 0; i < t.count; i++) order[t.first + i] = bestOrder[i];
+          sp.axis = -1; sp.nLeft = bestK;                // "split the (re-ordered) range at bestK"
+        }
+      }
       const float scale[3] = { sah_scale(t.cbLo.x, t.cbHi.x), sah_scale(t.cbLo.y, t.cbHi.y), sah_scale(t.cbLo.z, t.cbHi.z) };
       const float base[3] = { t.cbLo.x, t.cbLo.y, t.cbLo.z };
       auto cen = [&](int f, int a) { const v3 c = (lo[f] + hi[f]) * 0.5f; return a == 0 ? c.x : a == 1 ? c.y : c.z; };
-      if (t.count > leafSize && level < kSahLevels) {
+      if (!swept && !forced && t.count > leafSize && level < kSahLevels) {
         SahBins B;
         for (int a = 0; a < 3; a++) for (int b = 0; b < kSahBins; b++) { B.cnt[a][b] = 0; for (int k = 0; k < 3; k++) { B.lo[a][b][k] = float_to_ordered(1e37f); B.hi[a][b][k] = float_to_ordered(-1e37f); } }
         for (int i = 0; i < t.count; i++) {
@@ -154,13 +192,14 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   const float padAbs = 1e-5f * fmaxf_(fmaxf_(shi.x - slo.x, shi.y - slo.y), shi.z - slo.z) + 1e-30f;
   std::vector<uint64_t> keys(n);
   const int idxBits = lbvh_index_bits(n), bitsPerAxis = getenv("HOSTSIM_MORTON30") ? 10 : lbvh_bits_per_axis(n);
-  for (int f = 0; f < n; f++) keys[f] = morton_key(cen[f], clo, invExt, bitsPerAxis, idxBits, f);
+  for (int f = 0; f < n; f++) keys[f] = morton_key(cen[f], clo, invExt, bitsPerAxis, idxBits, f) | (tri_is_big(lo[f], hi[f], slo, shi) ? 0ull : kSmallKeyBit);
   std::sort(keys.begin(), keys.end());
   std::vector<KarrasNode> sahNodes; std::vector<int> sahParentI, sahParentL;
   const bool useSah = g_builder == 1 && n > 1;
   if (useSah) {
     std::vector<int> order(n);
     for (int k = 0; k < n; k++) order[k] = key_face(keys[k], idxBits);
+    g_forcedRootSplit = big_key_count(keys.data(), n);      // large triangles first (pt_lbvh.h kSmallKeyBit): the root's range is split between them and the others
     build_sah_topology(lo, hi, order, clo, chi, leafSize, sahNodes, sahParentI, sahParentL);
     for (int k = 0; k < n; k++) keys[k] = (uint64_t)order[k];              // the device keeps the face index only, too
   }

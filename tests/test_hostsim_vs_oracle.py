@@ -185,3 +185,15 @@ def test_compressed_nodes_on_random_triangle_soups(tmp_path, scale, offset):
     a64, c64 = hostsim_render(hs, seeds, node_format=64)
     assert np.array_equal(a128.view(np.uint32), a64.view(np.uint32)) and a128.max() > 0
     assert (c128["bounceRays"], c128["shadowRays"], c128["closestHits"]) == (c64["bounceRays"], c64["shadowRays"], c64["closestHits"])
+
+
+def test_host_mirror_trees_are_valid_and_the_check_sees_a_broken_box():
+    """tests/common.py tree_containment_errors (used by the GPU tests and the fuzzers' tree-dependence proof) on the host mirror
+    of the device builder: every child box -- 128-byte form and decoded 64-byte form -- contains the triangles below it; one shrunken box is found."""
+    from common import tree_containment_errors
+    hs = M.HostScene("million_standin", 64, 36, iarg=3000)
+    for leaf, builder in ((1, 1), (4, 1), (8, 1), (4, 0)):
+        n, t, _p, root, _depth, n64 = hostsim_bvh(hs, leaf, builder, want_nodes64=True)
+        assert tree_containment_errors(n, t, root, n64) == 0, (leaf, builder)
+    broken = n.copy(); broken.view(np.float32)[0, 12] -= 0.5          # hix of the root's child 0
+    assert tree_containment_errors(broken, t, root) == 1

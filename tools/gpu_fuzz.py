@@ -4,7 +4,7 @@ import os, sys, hashlib, random
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
-from common import M   # noqa: E402
+from common import M, tree_containment_errors   # noqa: E402
 ctx = M.Context(0)
 rng = random.Random(int(os.environ.get("SEED", "1")))
 cases = int(os.environ.get("CASES", "24"))
@@ -60,7 +60,12 @@ for case in range(cases):
         ctx.load(hs); ctx.accum_clear(); ctx.render(seeds)
         own = ctx.accum_read()
         if np.array_equal(own, got):
-            verdict = "TREE-DEPENDENT HIT (%d pixels; variant 0 on the candidate's tree gives the candidate's bits)" % int((ref != got).any(axis=-1).sum())
+            # ... and the candidate's tree itself must be VALID: every child box, 128-byte and decoded 64-byte form, contains the
+            # triangles below it -- a builder bug would make every kernel miss the same triangle and pass the check above
+            nodes_, tris_, _p = ctx.debug_read_accel()
+            invalid = tree_containment_errors(nodes_, tris_, 0 if len(nodes_) else -1, ctx.debug_read_nodes64())
+            verdict = ("TREE-DEPENDENT HIT (%d pixels; variant 0 on the candidate's tree gives the candidate's bits; every box of that tree contains its triangles)"
+                       % int((ref != got).any(axis=-1).sum())) if invalid == 0 else "MISMATCH (INVALID TREE: %d child boxes do not contain their triangles)" % invalid
         elif used == (4, 64):
             # the per-lane kernel walks the 128-byte boxes of the same tree; the candidate walked their quantised (larger) form
             ctx.set_option("kernel_variant", 4); ctx.set_option("node_format", 128)

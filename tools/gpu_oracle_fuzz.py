@@ -7,7 +7,7 @@ import os, sys, random, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
-from common import M, O, oracle_scene, rmse, hostsim_render   # noqa: E402
+from common import M, O, oracle_scene, rmse, hostsim_render , tree_containment_errors  # noqa: E402
 ctx = M.Context(0)
 rng = random.Random(int(os.environ.get("SEED", "1")))
 cases = int(os.environ.get("CASES", "24"))
@@ -53,7 +53,9 @@ for case in range(cases):
             c2.load(hs); c2.accum_clear(); st2 = c2.render_counted(seeds); g2 = c2.accum_read()[..., :3]; c2.close()
             if rmse(g2 / spp, o / spp) <= 2e-6 and st2.rays == ost.rays and st2.closestHits == ost.closestHits:
                 other = alt; break
-        if same_on_host and other is not None:
+        nodes_, tris_, _p = ctx.debug_read_accel()      # (3) the device's tree is a valid one: every child box contains the triangles below it
+        valid_tree = tree_containment_errors(nodes_, tris_, 0 if len(nodes_) else -1, ctx.debug_read_nodes64()) == 0
+        if same_on_host and other is not None and valid_tree:
             verdict = "TREE-DEPENDENT HIT (the CPU build of the kernel code gives the GPU's result on this tree; the GPU gives the oracle's with %s)" % other
             tree_cases += 1; ok = True
     worst = max(worst, e if verdict == "ok" else 0.0)
