@@ -141,9 +141,9 @@ def cpu_baseline(width, height, target_s):
 def read_traffic(repo, tag=None):
     """Counters of the trace kernel from the committed rocprofv3 PMC passes (collected separately: profiles/README.md,
     tools/prof_bench.sh + tools/make_traffic_json.py; tag = "c2" / "c4" / "c5": the passes of that BASELINE config,
-    profiles/r05_traffic_<tag>.json).  Only used when they were collected on THIS device code (source_hash); otherwise the
+    profiles/rNN_traffic_<tag>.json).  Only used when they were collected on THIS device code (source_hash); otherwise the
     fields are null rather than stale."""
-    p = os.path.join(repo, "profiles", "traffic.json" if not tag else "r05_traffic_%s.json" % tag)
+    p = os.path.join(repo, "profiles", "traffic.json") if not tag else os.path.join(repo, _latest("traffic_%s.json" % tag, os.path.join("profiles", "r05_traffic_%s.json" % tag)))
     try:
         t = json.load(open(p))
     except Exception:
@@ -247,7 +247,7 @@ def roofline_block(achieved_gbs, launch_ms, nlaunch, bytes_per_launch, bytes_per
 OTHER_CONFIGS = {"random_spheres": ("c2", 1, "random_spheres (analytic spheres + quads, NoAccel)"),
                  "dining_standin": ("c4", 3, "dining-room stand-in (multi-mesh, Disney BRDF; the asset is absent upstream)"),
                  "million_standin": ("c5", 4, "1 M-triangle glass knot stand-in (the asset is absent upstream)")}
-CONFIGS_FILE = os.path.join("profiles", "r05_configs.json")      # one bench.py line per BASELINE config (tools/r05_configs.sh)
+CONFIGS_FILE = _latest("configs.json", os.path.join("profiles", "r05_configs.json"))      # one bench.py line per BASELINE config (tools/prof_configs.sh <tag>)
 
 
 def workload_text(a):
@@ -258,7 +258,7 @@ def workload_text(a):
 
 
 def other_configs(repo):
-    """The committed bench.py lines of BASELINE configs 2, 4, 5 (profiles/r05_configs.json, written by tools/r05_configs.sh on MI355X):
+    """The committed bench.py lines of BASELINE configs 2, 4, 5 (the newest profiles/rNN_configs.json, written by tools/prof_configs.sh on MI355X):
     their rates and roofline fractions ride along in the headline's block so that one line says what limits each kernel."""
     try:
         rows = json.load(open(os.path.join(repo, CONFIGS_FILE)))
@@ -431,9 +431,9 @@ class GpuFrame:
 
     def first_frame(self):
         """A context's FIRST frame: no depth history orders its work yet, so the launch ends with the deepest paths walking alone
-        (csrc/drainkernel.hip takes them over).  Trace-kernel ms of one frame rendered like that (the kernel code is loaded: one
-        small launch first); the history is dropped again afterwards so that the counted launch that follows is a first frame, too."""
-        self.ctx.render(self.seeds[:1])
+        (csrc/drainkernel.hip takes them over).  Trace-kernel ms of one frame rendered like that (HIP events on the launch stream: the
+        host-side loading of the code object is not in it); the history is dropped again afterwards so that the counted launch that
+        follows is a first frame, too."""
         self.ctx.set_option("forget_history", 1)
         self.accum.zero_(); self.sync()
         self.ctx.kernel_time(reset=True)
@@ -565,7 +565,7 @@ class GpuFrame:
             return None
         if a.scene == "file:coffee" and (a.width, a.height, a.spp) == (1920, 1080, 256):
             return read_traffic(REPO)
-        if a.scene in OTHER_CONFIGS:                       # the PMC passes of tools/r05_configs.sh belong to one size per config
+        if a.scene in OTHER_CONFIGS:                       # the PMC passes of tools/prof_configs.sh belong to one size per config
             t = read_traffic(REPO, OTHER_CONFIGS[a.scene][0])
             if t and t.get("workload") == workload_text(a):
                 return t

@@ -854,6 +854,15 @@ int moptix_build_accel(moptix_context c, const char* kind) {
   if (!trbvh && strcmp(kind, "NoAccel")) return fail(c, MOPTIX_ERR_INVALID, std::string("unknown acceleration: ") + kind);
   const int nFaces = (int)c->faceMat.size();
   if (!trbvh && nFaces > 0) return fail(c, MOPTIX_ERR_INVALID, "NoAccel with triangle meshes is not supported; use Trbvh");
+  // Whatever happens below, the tree the context holds is not valid for the scene any more: a failed build must not leave accelBuilt set
+  // with a freed or stale tree behind it.
+  c->accelBuilt = false;
+  // The kernels address every scene table with a 32-bit byte offset from its base (pt_types.h at32) and a leaf reference holds its first
+  // record in 28 bits; the builder indexes triangles with 32-bit ints.  Checked on the INPUT, before anything is uploaded or built: the node
+  // table has at most one four-wide node per two triangles (pt_lbvh.h), so the triangle count bounds every table.
+  if ((unsigned long long)nFaces >= (1ull << 28) || (unsigned long long)nFaces * sizeof(Node128) / 2 >= (1ull << 32))
+    return fail(c, MOPTIX_ERR_LIMIT, "acceleration structure too large: triangle / node tables must stay below 4 GB (2^28 triangles at most)");
+  if ((unsigned long long)c->mats.size() * sizeof(DevMaterial) >= (1ull << 32)) return fail(c, MOPTIX_ERR_LIMIT, "material table must stay below 4 GB");
   HIPCHK(c, hipSetDevice(c->device), "hipSetDevice");
   HIPCHK(c, c->dMats.upload(c->mats, c->stream), "upload materials");
   HIPCHK(c, c->dSpheres.upload(c->spheres, c->stream), "upload spheres");
@@ -886,8 +895,7 @@ int moptix_build_accel(moptix_context c, const char* kind) {
     for (int m : c->faceMat) glassFaces += (c->mats[m].kind == MAT_GLASS || (c->mats[m].kind == MAT_DISNEY && c->mats[m].brdfType == BRDF_GLASS)) ? 1 : 0;
     c->glassFaceShare = (double)glassFaces / (double)nFaces;
     HIPCHK(c, lbvh_build(c->stream, c->dFacePos.p, c->dFaceNrm.p, c->dFaceHasNrm.p, c->dFaceMat.p, nFaces, c->optLeafSize, c->optBuilder, &c->bvh), "LBVH build");
-    // The kernels address every scene table with a 32-bit byte offset from its base (pt_types.h at32) and a leaf reference holds
-    // its first record in 28 bits: tables of 4 GB and more are refused here rather than wrapped there.
+    // (the same limits again on what was built: belt and braces)
     const unsigned long long lim = 1ull << 32;
     if ((unsigned long long)c->bvh.nTris * sizeof(Tri48) >= lim || (unsigned long long)c->bvh.nTris * sizeof(TriShade) >= lim ||
         (unsigned long long)c->bvh.nNodes * sizeof(Node128) >= lim || (unsigned long long)c->bvh.nTris >= (1ull << 28)) {
@@ -895,7 +903,6 @@ int moptix_build_accel(moptix_context c, const char* kind) {
       return fail(c, MOPTIX_ERR_LIMIT, "acceleration structure too large: triangle / node tables must stay below 4 GB (2^28 triangles at most)");
     }
   }
-  if ((unsigned long long)c->mats.size() * sizeof(DevMaterial) >= (1ull << 32)) return fail(c, MOPTIX_ERR_LIMIT, "material table must stay below 4 GB");
   HIPCHK(c, hipStreamSynchronize(c->stream), "sync after upload");
   c->formatDecided = false;            // choose_node_format at the next render: it needs the camera
   c->sceneDirty = false; c->accelBuilt = true;

@@ -172,16 +172,70 @@ static int g_debugPixel = getenv("HOSTSIM_DEBUG_PIXEL") ? atoi(getenv("HOSTSIM_D
 static int g_packet = 0;      // 1 = the per-bounce state machine of pt_packet.h (kernel variant 4) instead of the per-ray one
 static int g_builder = 1;     // 0 = Morton radix tree (Karras), 1 = binned SAH over the Morton order (device default)
 
+// HOSTSIM_ESC=<k> -- a YARDSTICK (tools/tree_yardstick.py), not the device's builder: early split clipping.  A triangle whose box is large for what
+// it holds -- a needle lying diagonally -- is referenced by several boxes, each the bounds of the triangle clipped to one half of the previous box
+// (longest axis, midpoint), until a box's surface area is at most k times the triangle's own area x 2 (a flat axis-aligned triangle has ratio ~1)
+// or 2^6 pieces; the tree is then built over REFERENCES.  Same triangle records (a triangle met twice ties with itself and is ignored).
+static void clip_bounds(const v3 tri[3], v3 blo, v3 bhi, v3& lo, v3& hi) {
+  // Sutherland-Hodgman against the six planes of the box, in double
+  double poly[16][3], tmp[16][3]; int np = 3;
+  for (int i = 0; i < 3; i++) { poly[i][0] = tri[i].x; poly[i][1] = tri[i].y; poly[i][2] = tri[i].z; }
+  const double bl[3] = { blo.x, blo.y, blo.z }, bh[3] = { bhi.x, bhi.y, bhi.z };
+  for (int a = 0; a < 3 && np > 0; a++)
+    for (int side = 0; side < 2 && np > 0; side++) {
+      const double plane = side ? bh[a] : bl[a]; const double sgn = side ? -1.0 : 1.0;
+      int nt = 0;
+      for (int i = 0; i < np; i++) {
+        const double* A = poly[i]; const double* B = poly[(i + 1) % np];
+        const double da = sgn * (A[a] - plane), db = sgn * (B[a] - plane);
+        if (da >= 0) { for (int k = 0; k < 3; k++) tmp[nt][k] = A[k]; nt++; }
+        if ((da >= 0) != (db >= 0)) { const double t = da / (da - db); for (int k = 0; k < 3; k++) tmp[nt][k] = A[k] + t * (B[k] - A[k]); tmp[nt][a] = plane; nt++; }
+      }
+      np = nt; for (int i = 0; i < np; i++) for (int k = 0; k < 3; k++) poly[i][k] = tmp[i][k];
+    }
+  if (np == 0) { lo = mk3(1e37f, 1e37f, 1e37f); hi = mk3(-1e37f, -1e37f, -1e37f); return; }
+  double l[3] = { 1e300, 1e300, 1e300 }, h[3] = { -1e300, -1e300, -1e300 };
+  for (int i = 0; i < np; i++) for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], poly[i][k]); h[k] = std::max(h[k], poly[i][k]); }
+  // outward in float, and never outside the box it was clipped to
+  lo = mk3(std::max(nextafterf((float)l[0], -1e37f), blo.x), std::max(nextafterf((float)l[1], -1e37f), blo.y), std::max(nextafterf((float)l[2], -1e37f), blo.z));
+  hi = mk3(std::min(nextafterf((float)h[0], 1e37f), bhi.x), std::min(nextafterf((float)h[1], 1e37f), bhi.y), std::min(nextafterf((float)h[2], 1e37f), bhi.z));
+}
+static void esc_split(const v3 tri[3], v3 lo, v3 hi, double triArea2, double k, int depth, int face, std::vector<int>& refFace, std::vector<v3>& rlo, std::vector<v3>& rhi) {
+  const double dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+  const double boxHalfArea = dx * dy + dy * dz + dz * dx;
+  if (depth >= 6 || boxHalfArea <= k * triArea2 || !(boxHalfArea > 0)) { refFace.push_back(face); rlo.push_back(lo); rhi.push_back(hi); return; }
+  const int a = dx >= dy && dx >= dz ? 0 : (dy >= dz ? 1 : 2);
+  const float mid = a == 0 ? 0.5f * (lo.x + hi.x) : a == 1 ? 0.5f * (lo.y + hi.y) : 0.5f * (lo.z + hi.z);
+  v3 hiL = hi, loR = lo;
+  if (a == 0) { hiL.x = mid; loR.x = mid; } else if (a == 1) { hiL.y = mid; loR.y = mid; } else { hiL.z = mid; loR.z = mid; }
+  v3 l0, h0, l1, h1;
+  clip_bounds(tri, lo, hiL, l0, h0); clip_bounds(tri, loR, hi, l1, h1);
+  if (l0.x <= h0.x) esc_split(tri, l0, h0, triArea2, k, depth + 1, face, refFace, rlo, rhi);
+  if (l1.x <= h1.x) esc_split(tri, l1, h1, triArea2, k, depth + 1, face, refFace, rlo, rhi);
+}
+
 static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
-  const int n = s.nFaces;
   out.nodes.clear(); out.nodes64.clear(); out.tris.clear(); out.shade.clear(); out.rootRef = kEmptyRef; out.depth = 0;
-  if (n <= 0) return;
-  std::vector<v3> lo(n), hi(n), cen(n);
+  if (s.nFaces <= 0) return;
+  // references: one per face, or (HOSTSIM_ESC) several clipped boxes of one face
+  std::vector<int> refFace; std::vector<v3> lo, hi;
+  const double esc = getenv("HOSTSIM_ESC") ? atof(getenv("HOSTSIM_ESC")) : 0.0;
+  for (int f = 0; f < s.nFaces; f++) {
+    const float* p = s.facePos + 9 * (size_t)f;
+    const v3 tri[3] = { mk3(p[0], p[1], p[2]), mk3(p[3], p[4], p[5]), mk3(p[6], p[7], p[8]) };
+    v3 l, h; tri_bounds(tri[0], tri[1], tri[2], l, h);
+    if (esc > 0.0) {
+      const v3 e0 = tri[1] - tri[0], e1 = tri[2] - tri[0]; const v3 c = cross(e0, e1);
+      const double area2 = std::sqrt((double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z);      // 2 x the triangle's area
+      esc_split(tri, l, h, area2, esc, 0, f, refFace, lo, hi);
+    } else { refFace.push_back(f); lo.push_back(l); hi.push_back(h); }
+  }
+  const int n = (int)refFace.size();
+  if (esc > 0.0 && getenv("HOSTSIM_DEBUG")) fprintf(stderr, "[hostsim] ESC %.2f: %d references for %d faces\n", esc, n, s.nFaces);
+  std::vector<v3> cen(n);
   v3 clo = mk3(1e37f, 1e37f, 1e37f), chi = mk3(-1e37f, -1e37f, -1e37f);
   v3 slo = clo, shi = chi;
   for (int f = 0; f < n; f++) {
-    const float* p = s.facePos + 9 * (size_t)f;
-    tri_bounds(mk3(p[0], p[1], p[2]), mk3(p[3], p[4], p[5]), mk3(p[6], p[7], p[8]), lo[f], hi[f]);
     cen[f] = (lo[f] + hi[f]) * 0.5f;
     clo = mk3(fminf_(clo.x, cen[f].x), fminf_(clo.y, cen[f].y), fminf_(clo.z, cen[f].z));
     chi = mk3(fmaxf_(chi.x, cen[f].x), fmaxf_(chi.y, cen[f].y), fmaxf_(chi.z, cen[f].z));
@@ -207,7 +261,7 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
   out.tris.resize(n); out.shade.resize(n);
   std::vector<v3> llo(n), lhi(n);
   for (int k = 0; k < n; k++) {
-    const int f = key_face(keys[k], idxBits);
+    const int r = key_face(keys[k], idxBits), f = refFace[r];
     const float* p = s.facePos + 9 * (size_t)f;
     const v3 p0 = mk3(p[0], p[1], p[2]), p1 = mk3(p[3], p[4], p[5]), p2 = mk3(p[6], p[7], p[8]);
     Tri48 t; memset(&t, 0, sizeof(t));
@@ -220,8 +274,8 @@ static void build_lbvh(const hostsim_scene& s, int leafSize, HostBVH& out) {
       sh.n0 = mk3(q[0], q[1], q[2]); sh.n1 = mk3(q[3], q[4], q[5]); sh.n2 = mk3(q[6], q[7], q[8]); sh.hasNormals = 1;
     }
     out.shade[k] = sh;
-    llo[k] = mk3(pad_lo(lo[f].x, padAbs), pad_lo(lo[f].y, padAbs), pad_lo(lo[f].z, padAbs));
-    lhi[k] = mk3(pad_hi(hi[f].x, padAbs), pad_hi(hi[f].y, padAbs), pad_hi(hi[f].z, padAbs));
+    llo[k] = mk3(pad_lo(lo[r].x, padAbs), pad_lo(lo[r].y, padAbs), pad_lo(lo[r].z, padAbs));
+    lhi[k] = mk3(pad_hi(hi[r].x, padAbs), pad_hi(hi[r].y, padAbs), pad_hi(hi[r].z, padAbs));
   }
   if (n <= leafSize) { out.rootRef = make_leaf_ref(0, n); return; }
 

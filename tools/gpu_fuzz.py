@@ -23,7 +23,8 @@ for case in range(cases):
     opts = dict(kernel_variant=rng.choice([3, 3, 4, 4]), leaf_size=rng.choice([1, 2, 4, 8]), tile_major=rng.choice([0, 1, 2, 3, 3]),
                 swap_lanes=rng.choice([8, 24, 48]), starve_lanes=rng.choice([4, 16, 40]), blocks_per_cu=rng.choice([1, 2, 3]),
                 sample_buffer_mb=rng.choice([1, 8192]), builder=rng.choice([0, 1, 1]), slots_in_use=rng.choice([-1, -1, 300, 64, 448, 509, 575, 576]),
-                aux_depth=rng.choice([0, 1, 1, 2, 3, 16]), node_format=rng.choice([0, 64, 64, 128]))
+                aux_depth=rng.choice([0, 1, 1, 2, 3, 16]), node_format=rng.choice([0, 64, 64, 128]),
+                drain_below=rng.choice([0, 1, 5, 16, 64, 64]))      # round 6: when the packet kernel's workgroups hand their last paths to the drain kernel
     if only >= 0 and case != only:
         continue
     for o in os.environ.get("OVERRIDE", "").split(","):   # replay with some options changed: which one does a mismatch need?

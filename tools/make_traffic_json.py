@@ -20,7 +20,7 @@ import bench   # noqa: E402
 
 src = sys.argv[1]
 dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "profiles", "traffic.json")
-bench_args = sys.argv[3].split() if len(sys.argv) > 3 else []      # the bench.py arguments the passes were made with (tools/r05_configs.sh): stamps the workload
+bench_args = sys.argv[3].split() if len(sys.argv) > 3 else []      # the bench.py arguments the passes were made with (tools/prof_configs.sh): stamps the workload
 agg, cnt = collections.defaultdict(float), collections.Counter()
 kernels = set()
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):

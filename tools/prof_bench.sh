@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the bench.py command (run on the GPU box via gpurun):
 #   kernel-trace --stats of `python3 bench.py` and separate PMC passes for HBM traffic.
 set -u
-TAG=${1:-r03}
+TAG=${1:?round tag, e.g. r06}
 OUT=gpurun_out/prof_bench_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -23,7 +23,7 @@ for d in sorted(glob.glob("$OUT/*/")):
         agg = collections.defaultdict(float); cnt = collections.Counter()
         for r in csv.DictReader(open(f)):
             k = (r.get("Kernel_Name", "")[:48], r.get("Counter_Name"))
-            if "queuekernel" not in k[0] and "packetkernel" not in k[0] and "reduce" not in k[0]: continue
+            if "queuekernel" not in k[0] and "packetkernel" not in k[0] and "drainkernel" not in k[0] and "reduce" not in k[0]: continue
             agg[k] += float(r.get("Counter_Value", 0)); cnt[k] += 1
         for k in sorted(agg): print("   %-48s %-24s sum=%.6g launches=%d per_launch=%.6g" % (k[0], k[1], agg[k], cnt[k], agg[k] / cnt[k]))
 PY
