@@ -48,6 +48,7 @@ def _latest(pattern, fallback):
 GATHER_CEILING_FILE = _latest("gather_ceiling.txt", os.path.join("profiles", "r03_gather_ceiling.txt"))    # output of tools/micro/gather on MI355X
 VALU_CEILING_FILE = _latest("valu_ceiling.txt", os.path.join("profiles", "r04_valu_ceiling.txt"))          # output of tools/micro/valu_issue on MI355X
 PIPELINE_FROM_RANKS = int(os.environ.get("MOPTIX_BENCH_PIPELINE_FROM", "8"))     # from this many ranks on the two-frames-in-flight mode is timed as well (after the one-frame mode)
+DRAIN_BELOW_DEFAULT = 64    # option drain_below as moptix_create leaves it (csrc/moptix_api.hip)
 PREFLIGHT_TIMEOUT_MS = int(os.environ.get("MOPTIX_BENCH_PREFLIGHT_MS", "30000"))
 COMM_TIMEOUT_MS = 120000
 KERNEL_WAVES_PER_SIMD = 3   # what the trace kernel's 168 registers and 53 KB of LDS allow (csrc/packetkernel.hip)
@@ -381,6 +382,10 @@ class GpuFrame:
         every rank makes its second communicator at the same point)."""
         self.flush()
         self.pipeline = mode == "two_in_flight"
+        # Two frames in flight run WITHOUT the drain kernel: a frame's drain kernel is queued behind its packet kernel, and by the time that one has
+        # ended the other frame's persistent grid has filled every CU (3 x 53 KB of LDS, 504 of 512 registers per SIMD) -- the drain kernel, and
+        # with it the frame's collective, would wait for a whole launch (measured: an 8-way share 43.7 ms with it, 41.1 without; profiles/r06_scaling_emulation.txt)
+        self.ctx.set_option("drain_below", 0 if self.pipeline else DRAIN_BELOW_DEFAULT)
         if self.pipeline and len(self.ctxs) == 1:
             a, torch = self.a, self.torch
             ctx2 = self.M.Context(self.local)
@@ -388,6 +393,7 @@ class GpuFrame:
                 ctx2.set_partition(self.part_rank, self.part_n)
             if getattr(self, "comm_blocking", 0):
                 ctx2.set_option("comm_blocking", 1)
+            ctx2.set_option("drain_below", 0)
             ctx2.load(self.hs)
             accum2 = torch.zeros(a.height * a.width * 3, dtype=torch.float32, device=self.device)
             ctx2.accum_bind(accum2.data_ptr())

@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(64) pt_drainkernel(const LaunchArgs a) {
         const v4 thrIn = slot_load(&cs->thr), radIn = slot_load(&cs->rad);
         const v4 na = slot_load(&cs->spare[0]), nb = slot_load(&cs->spare[1]);
         const int fl = f2i(nb.w);
+        if (CNT) atomicAdd(a.counters + 813, 1ull);
         const int nSh = (fl >> kPendShift) & 3;
         v4 wh = mk4(0.f, 0.f, 0.f, 0.f), wb = mk4(1.f, 1.f, 1.f, 1.f);
         if (fl & kHitValid) wh = slot_load(&cs->hit);
@@ -180,6 +181,7 @@ __global__ void __launch_bounds__(64) pt_drainkernel(const LaunchArgs a) {
           atomicAdd(a.counters + 40 + b, 1ull); atomicMax(a.counters + 296 + b, (unsigned long long)ps.depth); atomicAdd(a.counters + 552 + b, (unsigned long long)ps.depth);
         }
         store_sample(a, ps.item, ps.accum);
+        if (CNT) atomicAdd(a.counters + 814, 1ull);
         if (a.tileCost != nullptr && ps.depth >= kDeepPath) atomicMax(a.tileCost + ((ps.item % a.nItems) >> a.unitShift), (unsigned int)ps.depth);
         ps.mode = M_DONE;
       }

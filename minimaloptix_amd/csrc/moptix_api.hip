@@ -282,6 +282,7 @@ int read_stats(moptix_context c, moptix_stats* stats) {
       fprintf(stderr, "[moptix] slot-record rows (16 B each) per ray: shading visit loads %.2f stores %.2f | leaf pass loads %.2f stores %.2f | total %.1f B per ray in %.2f shading visits and %.2f leaf visits per ray\n",
               h[808] / rays, h[809] / rays, h[810] / rays, h[811] / rays, 16.0 * (double)(h[808] + h[809] + h[810] + h[811]) / rays, (double)h[12] / rays, (double)h[23] / rays);
     }
+    if (c->dCounters.n >= 816 && (h[812] | h[813])) fprintf(stderr, "[moptix] hand-over: %llu paths handed over by the packet kernel, %llu taken by the drain kernel; samples finished: %llu by the packet kernel + %llu by the drain kernel (of %llu)\n", h[812], h[813], h[815], h[814], h[0]);
     if (h[22]) fprintf(stderr, "[moptix] node steps %llu (%.1f lanes avg), leaf passes %llu (%.1f lanes avg)\n", h[9] - h[22],
             (double)(h[10] - h[23]) / (double)(h[9] - h[22]), h[22], (double)h[23] / (double)h[22]);
     if (c->dCounters.n >= 816 + 2 * kCensusRegions && h[816 + kCensusRegions]) {      // lane census of the divergent regions (pt_path.h census<>)

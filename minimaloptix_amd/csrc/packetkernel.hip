@@ -301,7 +301,11 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
       if (threadIdx.x == 0) {
         for (int q = 0; q < kNumQ; q++) { W.qHead[q] = 0; W.qCount[q] = 0; }
         W.qCount[Q_GEN] = nUse; const int below = a.workCounter[kDrainList + kDrainBelow];
-        W.done = NS - nUse; W.drainAt = below > 0 ? max(0, NS - below) : 0x7fff; W.lock = 0;
+        // drainAt: "slots without a path" from which on the pool hands over.  Slots that never carried a path (NS - nUse) are in that count from the
+        // start, so the threshold is at least one above it: a slot only joins the count when it has found the work counter exhausted, and a pool
+        // must never stop shading while work items are left (slots_in_use <= drain_below would otherwise drain from the first transaction on,
+        // with most of the launch's items unrendered -- found by the option fuzzer, seed 103 case 252)
+        W.done = NS - nUse; W.drainAt = below > 0 ? max(NS - below, NS - nUse + 1) : 0x7fff; W.lock = 0;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
@@ -553,6 +557,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
           atomicAdd(a.counters + 40 + b, 1ull); atomicMax(a.counters + 296 + b, (unsigned long long)ps.depth); atomicAdd(a.counters + 552 + b, (unsigned long long)ps.depth);
         }
         store_sample(a, ps.item, ps.accum);
+        if (CNT) atomicAdd(a.counters + 815, 1ull);
         if (a.tileCost != nullptr && ps.depth >= kDeepPath) atomicMax(a.tileCost + ((ps.item % a.nItems) >> a.unitShift), (unsigned int)ps.depth);
         ps.mode = M_NEW_PIXEL;
       }
@@ -847,6 +852,7 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
         int* dl = a.workCounter + kDrainList;
         const int idx = atomicAdd(dl + (deep ? kDrainDeepN : kDrainOtherN), 1);
         dl[deep ? kDrainEntries + idx : kDrainEntries + dl[kDrainCap] - 1 - idx] = gpool * NS + slot;
+        if (CNT) atomicAdd(a.counters + 812, 1ull);
       }
     }
   }

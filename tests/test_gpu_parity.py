@@ -532,21 +532,21 @@ def test_drain_kernel_changes_nothing(gpu_ctx, scene, kw, size):
     out = {}
     try:
         gpu_ctx.set_option("kernel_variant", 4)
-        for db in (0, 4, 64):
-            gpu_ctx.set_option("drain_below", db)
+        for db, slots in ((0, -1), (4, -1), (64, -1), (64, 64)):      # the last one: fewer slots in use than the threshold (the pool must not drain before the work items run out)
+            gpu_ctx.set_option("drain_below", db); gpu_ctx.set_option("slots_in_use", slots)
             gpu_ctx.load(hs); gpu_ctx.accum_clear()
             st = gpu_ctx.render_counted(seeds)
             if gpu_ctx.get_option("kernel_variant_used") != 4:
                 pytest.skip("scene outside the packet kernel's limits")
-            out[db] = (gpu_ctx.accum_read(), st)
+            out[(db, slots)] = (gpu_ctx.accum_read(), st)
             gpu_ctx.accum_clear(); gpu_ctx.render(seeds)                       # the uncounted instantiation
-            assert np.array_equal(gpu_ctx.accum_read().view(np.uint32), out[db][0].view(np.uint32))
+            assert np.array_equal(gpu_ctx.accum_read().view(np.uint32), out[(db, slots)][0].view(np.uint32))
     finally:
-        gpu_ctx.set_option("drain_below", DRAIN_DEFAULT); gpu_ctx.set_option("kernel_variant", -1)
-    a0, s0 = out[0]
-    for db in (4, 64):
+        gpu_ctx.set_option("drain_below", DRAIN_DEFAULT); gpu_ctx.set_option("kernel_variant", -1); gpu_ctx.set_option("slots_in_use", -1)
+    a0, s0 = out[(0, -1)]
+    for db in ((4, -1), (64, -1), (64, 64)):
         a, st = out[db]
-        assert np.array_equal(a.view(np.uint32), a0.view(np.uint32)), "drain_below %d changed the image" % db
+        assert np.array_equal(a.view(np.uint32), a0.view(np.uint32)), "drain_below / slots_in_use %s changed the image" % (db,)
         assert (st.rays, st.shadowRays, st.closestHits, st.samples) == (s0.rays, s0.shadowRays, s0.closestHits, s0.samples)
 
 

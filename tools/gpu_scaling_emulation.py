@@ -15,6 +15,8 @@ for o in os.environ.get("OPTS", "").split(","):
 NS = [int(x) for x in os.environ.get("NS", "2,4,8").split(",")]
 PIPE = os.environ.get("PIPE", "0") == "1"          # two frames in flight: two contexts render alternate frames of the share (bench.py's default from 8 ranks on)
 ctx2 = M.Context(0) if PIPE else None
+if PIPE:                                           # two frames in flight run without the drain kernel (bench.py GpuFrame.set_mode says why)
+    ctx.set_option("drain_below", 0); ctx2.set_option("drain_below", 0)
 if ctx2:
     for o in os.environ.get("OPTS", "").split(","):
         if "=" in o:
