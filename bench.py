@@ -681,7 +681,18 @@ def run_rank(a, frame_cls=GpuFrame):
                 fr.set_mode(mode)
                 if mode == "two_in_flight" and hasattr(fr, "preflight"):
                     failed = fr.preflight(which=1)                      # the second communicator, made just now
-            if not failed:
+        except Exception as e:
+            failed = "%s: %s" % (type(e).__name__, e)
+        # every rank says how entering the mode went BEFORE anyone starts a frame: a rank that could not must not leave the others waiting in
+        # a collective for it
+        said = everyone(failed)
+        if any(said):
+            results[mode] = {"error": "; ".join("rank %d: %s" % (i, t) for i, t in enumerate(said) if t)}
+            if not any("ms_per_step" in r for r in results.values()):
+                break
+            continue
+        try:
+            if True:
                 for _ in range(a.warmup):
                     fr.step()
                 fr.flush()

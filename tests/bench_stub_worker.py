@@ -38,6 +38,27 @@ class StubFrame:
     def sync(self):
         pass
 
+    # ---- the hooks of bench.run_rank that GpuFrame has (modes, pre-flight, fall-back), driven by the environment of the test ----
+    def modes(self):
+        return ["one_frame", "two_in_flight"] if os.environ.get("BENCH_STUB_MODES") == "2" else ["one_frame"]
+
+    def set_mode(self, mode):
+        self.pipeline = mode == "two_in_flight"
+        if self.pipeline and os.environ.get("BENCH_STUB_FAIL_MODE_B") and self.rank == 1:
+            raise RuntimeError("stub: the second mode cannot start on rank 1")
+
+    def preflight(self, which=None):
+        fail = os.environ.get("BENCH_STUB_FAIL_PREFLIGHT", "")          # "once": the first communicator kind fails on rank 1; "always": every kind
+        if self.rank == 1 and (fail == "always" or (fail == "once" and not getattr(self, "comm_blocking", 0))):
+            return "stub: rank 1 cannot complete a collective"
+        return None
+
+    def reinit_comm(self, blocking):
+        self.comm_blocking = 1 if blocking else 0
+
+    def comm_kind(self):
+        return "stub, %s" % ("blocking" if getattr(self, "comm_blocking", 0) else "non-blocking")
+
     def _render(self):
         img, c = hostsim_render(self.hs, self.seeds)
         flat = img.reshape(-1, 3)

@@ -135,3 +135,50 @@ def test_gpus_2_launcher_path_on_cpu(tmp_path, split):
         assert np.array_equal(got, ref)
     else:
         assert np.allclose(got, ref, rtol=0, atol=2e-6 * spp)
+
+
+def _stub_two_ranks(tmp_path, extra_env, split="tile"):
+    w, h, spp = 40, 24, 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["BENCH_STUB_FRAME"] = str(tmp_path / "frame.npy"); env["OMP_NUM_THREADS"] = "2"
+    env.update(extra_env)
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--width", str(w), "--height", str(h), "--spp", str(spp), "--scene", "spheres", "--no-cpu-baseline", "--split", split]
+    code = ("import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.launch_workers(2, %r, script=%r))"
+            % (REPO, argv, os.path.join(REPO, "tests", "bench_stub_worker.py")))
+    out_file = tmp_path / "out.txt"
+    with open(out_file, "w") as fh:
+        rc = subprocess.call([sys.executable, "-c", code], env=env, stdout=fh, stderr=subprocess.STDOUT, timeout=600)
+    text = out_file.read_text()
+    return rc, [json.loads(l) for l in text.splitlines() if l.startswith("{")], text
+
+
+def test_two_ranks_on_cpu_both_modes_in_one_line(tmp_path):
+    """bench.run_rank's round-6 control flow on CPU (gloo, two ranks, the stand-in renderer): both modes timed in one run, K steps each; the line
+    carries both and reports the better one."""
+    rc, lines, text = _stub_two_ranks(tmp_path, {"BENCH_STUB_MODES": "2"})
+    assert rc == 0 and len(lines) == 1, text[-2000:]
+    d = lines[0]
+    modes = d["config"]["modes"]
+    assert set(modes) == {"one_frame", "two_in_flight"} and all(m["ms_per_frame"] > 0 for m in modes.values())
+    assert d["config"]["mode"] == min(modes, key=lambda m: modes[m]["ms_per_frame"]) and d["pmc_live"] is False
+    assert d["config"]["communicator"] == "stub, non-blocking" and d["config"]["communicator_note"] is None
+
+
+def test_two_ranks_on_cpu_a_failing_second_mode_leaves_the_first_standing(tmp_path):
+    rc, lines, text = _stub_two_ranks(tmp_path, {"BENCH_STUB_MODES": "2", "BENCH_STUB_FAIL_MODE_B": "1"})
+    assert rc == 0 and len(lines) == 1, text[-2000:]
+    d = lines[0]
+    assert d["config"]["mode"] == "one_frame" and d["value"] > 0
+    assert "rank 1" in d["config"]["modes"]["two_in_flight"]["error"] and "ms_per_frame" in d["config"]["modes"]["one_frame"]
+
+
+def test_two_ranks_on_cpu_preflight_falls_back_once_then_gives_up_with_a_line(tmp_path):
+    """A pre-flight collective that fails on one rank: every rank makes the other kind of communicator once (the note says so); if that fails too,
+    rank 0 prints ONE line with "error" and each rank's diagnosis and the launcher exits non-zero."""
+    rc, lines, text = _stub_two_ranks(tmp_path, {"BENCH_STUB_FAIL_PREFLIGHT": "once"})
+    assert rc == 0 and len(lines) == 1, text[-2000:]
+    assert "pre-flight failed with the non-blocking communicator" in lines[0]["config"]["communicator_note"] and lines[0]["config"]["communicator"] == "stub, blocking"
+    rc, lines, text = _stub_two_ranks(tmp_path, {"BENCH_STUB_FAIL_PREFLIGHT": "always"})
+    assert rc != 0 and len(lines) == 1, text[-2000:]
+    d = lines[0]
+    assert d["value"] is None and "pre-flight" in d["error"] and d["config"]["ranks"]["diagnosis"][0].endswith("ok") and "rank 1" in d["config"]["ranks"]["diagnosis"][1]
