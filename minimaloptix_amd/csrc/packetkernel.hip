@@ -891,22 +891,39 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_packetkernel(
 
 }  // namespace
 
+// The instantiations are compiled in two translation units, by node format: this file holds the 64-byte-node kernels (the benchmark scene's), and
+// packetkernel_n128.hip includes it with PT_PK_N128 for the 128-byte-node ones.  The reason is the compiler, not the code: LLVM's instruction
+// scheduling strategy is a per-file flag (Makefile), "max-ilp" is 0.85 % faster than the default on the 64-byte kernels (coffee 312.5 -> 309.9 ms,
+// glass knot -1.5 %) and 2-4 % SLOWER on the 128-byte ones (dining room) and on the queue kernels (random spheres) -- measured, round 6.
+#ifndef PT_PK_N128
 int packetkernel_lds_stack_entries() { return kStackN; }
 int packetkernel_slots() { return kP * kWaves; }
 size_t packetkernel_cold_bytes(int nBlocks) { return (size_t)nBlocks * kWaves * kP * sizeof(SlotCold); }
 size_t packetkernel_overflow_ints(int nBlocks, int ovfDepth) { return (size_t)nBlocks * kWaves * kP * (size_t)ovfDepth; }
+constexpr bool kThisFileN64 = true;
+#define PT_PK_LAUNCH launch_packetkernel_n64
+#else
+constexpr bool kThisFileN64 = false;
+#define PT_PK_LAUNCH launch_packetkernel_n128
+#endif
 
 template <bool CNT, bool FAST>
 static void launch_pk(dim3 grid, dim3 block, hipStream_t stream, const LaunchArgs& a) {
-  const bool n64 = a.scene.nodes64 != nullptr;      // moptix_api.hip fill_view: the option node_format
-  if (a.scene.shadowNearest) { if (n64) pt_packetkernel<CNT, true, FAST, true, true><<<grid, block, 0, stream>>>(a); else pt_packetkernel<CNT, true, FAST, true, false><<<grid, block, 0, stream>>>(a); }
-  else                       { if (n64) pt_packetkernel<CNT, true, FAST, false, true><<<grid, block, 0, stream>>>(a); else pt_packetkernel<CNT, true, FAST, false, false><<<grid, block, 0, stream>>>(a); }
+  if (a.scene.shadowNearest) pt_packetkernel<CNT, true, FAST, true, kThisFileN64><<<grid, block, 0, stream>>>(a);
+  else                       pt_packetkernel<CNT, true, FAST, false, kThisFileN64><<<grid, block, 0, stream>>>(a);
 }
-hipError_t launch_packetkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading) {
+hipError_t PT_PK_LAUNCH(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading) {
   dim3 grid(nBlocks), block(kBlockThreads);
   if (fastShading) { if (counted) launch_pk<true, true>(grid, block, stream, a); else launch_pk<false, true>(grid, block, stream, a); }
   else             { if (counted) launch_pk<true, false>(grid, block, stream, a); else launch_pk<false, false>(grid, block, stream, a); }
   return hipGetLastError();
 }
+#ifndef PT_PK_N128
+hipError_t launch_packetkernel_n128(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading);
+hipError_t launch_packetkernel(hipStream_t stream, const LaunchArgs& a, int nBlocks, bool counted, bool fastShading) {
+  // moptix_api.hip fill_view: the option node_format decides whether the scene view carries the 64-byte nodes
+  return a.scene.nodes64 != nullptr ? launch_packetkernel_n64(stream, a, nBlocks, counted, fastShading) : launch_packetkernel_n128(stream, a, nBlocks, counted, fastShading);
+}
+#endif
 
 }  // namespace pt

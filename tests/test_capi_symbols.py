@@ -64,11 +64,11 @@ def test_trace_kernel_resources_are_pinned():
     assert len(bench) == 1, sorted(res)[:5]
     r = bench[0]
     assert r["vgpr_count"] <= 168, r                       # three workgroups of four waves per CU
-    # pinned at today's numbers (round 6: 6 vector, 53 scalar -- the hand-over block behind the main loop moved four more vector registers
-    # to scratch and four scalar ones back, measured at the same frame time as round 5's 2 / 57; round 3: 11 / 111): an edit that moves them
-    # has to say so here and in profiles/r06_kernel_resources.txt, where the numbers are kept per round
-    assert r["vgpr_spill_count"] <= 6, r
-    assert r["sgpr_spill_count"] <= 53, r
+    # pinned at today's numbers (round 6: 4 vector, 61 scalar under LLVM's "max-ilp" scheduling strategy, which this file's 64-byte-node kernels are
+    # built with since it measured 0.85 % faster than the default's 6 / 53; round 5: 2 / 57; round 3: 11 / 111): an edit that moves them has to say so
+    # here and in profiles/r06_kernel_resources.txt, where the numbers are kept per round
+    assert r["vgpr_spill_count"] <= 4, r
+    assert r["sgpr_spill_count"] <= 61, r
     # LDS: three workgroups per CU.  The CU hands LDS out in blocks of 1,280 bytes: 42 blocks = 53,760 bytes each (54,128 bytes ran two
     # workgroups per CU in round 4 -- frame 105 instead of 79 ms -- although hipOccupancyMaxActiveBlocksPerMultiprocessor says 3 up to 54,592)
     assert r["group_segment_fixed_size"] <= 53760, r

@@ -12,7 +12,7 @@ FAST = {"v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_sub
 TRANS = {"v_rcp_f32", "v_sqrt_f32", "v_rsq_f32"}
 with tempfile.TemporaryDirectory() as d:
     asm = os.path.join(d, "pk.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off", "-include", "cstring",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-include", "cstring",
                            "-I" + os.path.join(REPO, "include"), "-S", "--cuda-device-only", os.path.join(REPO, "minimaloptix_amd", "csrc", "packetkernel.hip"), "-o", asm],
                           stderr=subprocess.DEVNULL)
     txt = open(asm).read().split("\n")
