@@ -40,6 +40,10 @@ constexpr int kRidMask = kDR - 1;       // a frontier entry keeps its ray id in 
 constexpr int kCap = 1536;              // frontier entries
 constexpr int kMargin = 160;            // room kept for a depth-first descent when the frontier is nearly full (3 pushes per level)
 constexpr unsigned int kNoPrim = 0x7fffffffu;
+// A wave that walks one or two paths -- the launch's very end, where every microsecond of a bounce is exposed 257 times -- pays two rounds for the root and its
+// children with one to four lanes busy.  The root's grandchildren and their boxes (<= 16 entries, from the 128-byte nodes) sit in LDS instead, and while the wave
+// holds at most kTop rays each ray starts there: (ray, entry) pairs tested in one round without a fetch.  Order and starting level change the work, not a result.
+constexpr int kTop = 16;
 
 struct DrainLds {
   int ref[kCap];                        // node index (>= 0) or leaf reference (< 0)
@@ -52,6 +56,9 @@ struct DrainLds {
   int bestTri[kDR], bestCls[kDR], bestMat[kDR];
   float beta[kDR], gamma[kDR];
   int dead[kDR];                        // shadow ray terminated by an opaque surface (scenes without glass)
+  // the tree's second level (the root's children's children, <= kTop of them) with their boxes: where a ray starts while the wave holds few rays
+  float topBox[kTop][6]; int topRef[kTop]; int nTop;
+  int rayList[kTop];                    // the ids of the rays in flight, compact
 };
 
 __device__ __forceinline__ int lane_prefix(unsigned long long mask) {
@@ -114,6 +121,27 @@ __global__ void __launch_bounds__(64) pt_drainkernel(const LaunchArgs a) {
   if (total == 0) return;
   const SlotCold* cold = reinterpret_cast<const SlotCold*>(a.poolCold);
   const int triBase = sc.nSpheres + sc.nQuads;
+
+  if (lane == 0) {
+    int n = 0;
+    if (sc.rootRef >= 0 && sc.rootRef != kEmptyRef) {
+      const Node128 r = load_const(at32(sc.nodes, sc.rootRef));
+      auto put = [&](const Node128& nd, int c) {
+        const float* f = reinterpret_cast<const float*>(&nd);      // lox loy loz hix hiy hiz, four children each
+        for (int k = 0; k < 6; k++) S.topBox[n][k] = f[4 * k + c];
+        S.topRef[n] = nd.ref[c]; n++;
+      };
+      for (int c1 = 0; c1 < r.count; c1++) {
+        if (r.ref[c1] == kEmptyRef) continue;
+        if (r.ref[c1] >= 0) {
+          const Node128 m = load_const(at32(sc.nodes, r.ref[c1]));
+          for (int c2 = 0; c2 < m.count; c2++) if (m.ref[c2] != kEmptyRef) put(m, c2);
+        } else put(r, c1);                                          // a leaf right under the root
+      }
+    }
+    S.nTop = n;
+  }
+  __syncthreads();
 
   Counters ct = {};
   uint32_t rounds = 0, roundLanes = 0;
@@ -225,11 +253,37 @@ __global__ void __launch_bounds__(64) pt_drainkernel(const LaunchArgs a) {
       }
     }
     int sp = 0;
-    if (sc.rootRef != kEmptyRef) {           // one frontier entry per ray, at the root
+    if (sc.rootRef != kEmptyRef) {
       const unsigned long long m0 = __ballot(nR > 0), m1 = __ballot(nR > 1), m2 = __ballot(nR > 2), m3 = __ballot(nR > 3);
       const int off = lane_prefix(m0) + lane_prefix(m1) + lane_prefix(m2) + lane_prefix(m3);
-      for (int j = 0; j < nR; j++) { S.ref[off + j] = sc.rootRef; S.tn[off + j] = i2f((f2i(sc.epsT) & ~kRidMask) | (lane * 4 + j)); }
-      sp = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+      const int nRays = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+      const int nT = S.nTop;
+      if (nT > 0 && nRays <= kTop) {         // few rays: each starts at the tree's second level (kTop above)
+        for (int j = 0; j < nR; j++) S.rayList[off + j] = lane * 4 + j;
+        __syncthreads();
+        const int pairs = nRays * nT;
+        for (int base = 0; base < pairs; base += 64) {
+          const int idx = base + lane;
+          bool in = false; int rid = 0, e = 0; float tn = 0.f;
+          if (idx < pairs) {
+            const int r = idx / nT; e = idx - r * nT; rid = S.rayList[r];
+            const float tb = i2f((int32_t)(S.best[rid] >> 32));
+            float tf = tb; tn = sc.epsT;
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+              const float a = fma_(S.topBox[e][ax], S.inv[rid][ax], S.noi[rid][ax]), b = fma_(S.topBox[e][3 + ax], S.inv[rid][ax], S.noi[rid][ax]);
+              tn = fmaxf_(tn, fminf_(a, b)); tf = fminf_(tf, fmaxf_(a, b));
+            }
+            in = tn <= tf * 1.0000005f;
+          }
+          const unsigned long long m = __ballot(in);
+          if (in) { const int w = sp + lane_prefix(m); S.ref[w] = S.topRef[e]; S.tn[w] = i2f((f2i(tn) & ~kRidMask) | rid); }
+          sp += __popcll(m);
+        }
+      } else {                               // one frontier entry per ray, at the root
+        for (int j = 0; j < nR; j++) { S.ref[off + j] = sc.rootRef; S.tn[off + j] = i2f((f2i(sc.epsT) & ~kRidMask) | (lane * 4 + j)); }
+        sp = nRays;
+      }
     }
     __syncthreads();
 
