@@ -4,7 +4,7 @@ import os, sys, hashlib, random
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
-from common import M, tree_containment_errors   # noqa: E402
+from common import M, tree_containment_errors, hostsim_render, hostsim_lib   # noqa: E402
 ctx = M.Context(0)
 rng = random.Random(int(os.environ.get("SEED", "1")))
 cases = int(os.environ.get("CASES", "24"))
@@ -71,8 +71,27 @@ for case in range(cases):
             # the per-lane kernel walks the 128-byte boxes of the same tree; the candidate walked their quantised (larger) form
             ctx.set_option("kernel_variant", 4); ctx.set_option("node_format", 128)
             ctx.load(hs); ctx.accum_clear(); ctx.render(seeds)
-            verdict = "MISMATCH (the 64-byte nodes differ from the 128-byte nodes of the same tree: decode bug, or a grazing hit the larger boxes admit -- replay with ONLY=%d and tools/gpu_fuzz_pixel.py)" % case \
-                if np.array_equal(ctx.accum_read(), own) else "MISMATCH"
+            if np.array_equal(ctx.accum_read(), own):
+                # The 64-byte nodes of this tree give another image than its 128-byte nodes: a decode bug -- or a grazing hit that only the
+                # quantised (larger) boxes admit.  Proof of the second: the CPU build of the kernel's own code (tests/hostsim, plain per-lane
+                # walk) on the SAME 64-byte nodes gives the candidate's values at the differing pixels, on the 128-byte nodes the reference's,
+                # the tree is valid, and the damage is a pixel or two.
+                diff = (got != own).any(axis=-1)
+                hostsim_lib().hostsim_set_builder(int(opts.get("builder", 1)))
+                h64, _c = hostsim_render(hs, seeds, leaf_size=int(opts.get("leaf_size", 4)), node_format=64)
+                hostsim_lib().hostsim_set_builder(int(opts.get("builder", 1)))
+                h128, _c = hostsim_render(hs, seeds, leaf_size=int(opts.get("leaf_size", 4)), node_format=128)
+                hostsim_lib().hostsim_set_builder(1)
+                nodes_, tris_, _p = ctx.debug_read_accel()
+                valid = tree_containment_errors(nodes_, tris_, 0 if len(nodes_) else -1, ctx.debug_read_nodes64()) == 0
+                same64 = float(np.abs(h64[diff] - got[diff]).max()) <= 1e-5 * spp
+                same128 = float(np.abs(h128[diff] - own[diff]).max()) <= 1e-5 * spp
+                verdict = ("TREE-DEPENDENT HIT (%d pixels; the 64-byte boxes admit a grazing hit the 128-byte boxes of the same tree cull: the CPU build of the kernel code gives the "
+                           "candidate's values on the 64-byte nodes and the reference's on the 128-byte nodes; the tree is valid)" % int(diff.sum())) \
+                    if (same64 and same128 and valid and int(diff.sum()) <= 2) else \
+                    "MISMATCH (the 64-byte nodes differ from the 128-byte nodes of the same tree and the CPU build does not reproduce it: same64 %s same128 %s valid %s pixels %d -- replay with ONLY=%d)" % (same64, same128, valid, int(diff.sum()), case)
+            else:
+                verdict = "MISMATCH"
         else:
             verdict = "MISMATCH"
         tree_cases += verdict.startswith("TREE"); ok = verdict.startswith("TREE")

@@ -10,14 +10,18 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAST = {"v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32",
         "v_lshrrev_b32", "v_ashrrev_i32", "v_mul_legacy_f32", "v_addc_co_u32", "v_add_co_u32"}
 TRANS = {"v_rcp_f32", "v_sqrt_f32", "v_rsq_f32"}
-with tempfile.TemporaryDirectory() as d:
-    asm = os.path.join(d, "pk.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-include", "cstring",
-                           "-I" + os.path.join(REPO, "include"), "-S", "--cuda-device-only", os.path.join(REPO, "minimaloptix_amd", "csrc", "packetkernel.hip"), "-o", asm],
-                          stderr=subprocess.DEVNULL)
-    txt = open(asm).read().split("\n")
+def assembly(src, flags):
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, "pk.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off"] + flags + ["-include", "cstring",
+                               "-I" + os.path.join(REPO, "include"), "-S", "--cuda-device-only", os.path.join(REPO, "minimaloptix_amd", "csrc", src), "-o", asm],
+                              stderr=subprocess.DEVNULL)
+        return open(asm).read().split("\n")
+# as the Makefile builds them: the 64-byte-node instantiations with LLVM's max-ilp scheduling (packetkernel.hip), the 128-byte-node ones with the default (packetkernel_n128.hip)
+ASM = {"1": assembly("packetkernel.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]), "0": assembly("packetkernel_n128.hip", [])}
 for n64, label in (("1", "64-byte nodes (the benchmark's instantiation pt_packetkernel<false,true,false,false,true>)"), ("0", "128-byte nodes fetched by the ray's signs (<false,true,false,false,false>)")):
     name = "_ZN2pt12_GLOBAL__N_115pt_packetkernelILb0ELb1ELb0ELb0ELb%sEEEvNS_10LaunchArgsE" % n64
+    txt = ASM[n64]
     start = [i for i, l in enumerate(txt) if l.startswith(name + ":")][0]
     end = [i for i, l in enumerate(txt) if i > start and l.startswith(".Lfunc_end")][0]
     body = txt[start:end]
