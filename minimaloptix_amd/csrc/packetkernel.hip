@@ -26,6 +26,11 @@
 //     registers while the node loop runs;
 //   * 576 path slots x 9 LDS stack entries per workgroup: rings sized exactly, 53,104 of the 53,760 bytes three workgroups per CU get.
 //
+//   * round 6: a workgroup that is down to its last paths (the launch's drain) stops shading partial batches and, once every path it has left waits in
+//     Q_SHADE / Q_GEN, hands them to drainkernel.hip BEHIND the main loop and leaves (the block after the loop says why it is there and not in it);
+//   * this file is compiled twice (Makefile): as it stands for the 64-byte-node instantiations, with LLVM's max-ilp scheduling, and through
+//     packetkernel_n128.hip (PT_PK_N128) for the 128-byte-node ones with the default strategy -- each is a few per cent slower under the other's.
+//
 // Limits (moptix_api.hip falls back to variant 3 otherwise): at most kPacketShadows lights, no Disney material on an
 // analytic primitive (shadow rays then need the brute-force lists at every ray start).
 #include <hip/hip_runtime.h>

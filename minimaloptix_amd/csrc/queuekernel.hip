@@ -172,6 +172,16 @@ __device__ __forceinline__ int route(int node, int kind, int bestPrim) {
 
 // NEAR: the scene has a Disney GLASS material, shadow rays keep their nearest any-hit candidate (pt_path.h, rule D5).  A template
 // parameter so that scenes without one -- the benchmark scene -- run code in which that logic does not exist.
+// The launch arguments again, through a pointer the compiler cannot see through (packetkernel.hip fresh_args has the whole story): a pass that needs the
+// scene takes its own copy -- s_load where used, dead when the pass ends -- instead of ~100 loop-invariant words living in scalar registers for the whole launch
+// and the scheduler's own scalar state in lanes of spill registers (round 6: this kernel shipped with 118-120 spilled scalar registers).
+__device__ __forceinline__ const LaunchArgs& fresh_args() {
+  typedef __attribute__((address_space(4))) const LaunchArgs CA;
+  unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const LaunchArgs*)(CA*)p;
+}
+
 template <bool CNT, bool SHARED, bool FAST = false, bool NEAR = false>
 __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(const LaunchArgs a) {
   constexpr int NS = SHARED ? kP * kWaves : kP;          // slots per pool
@@ -290,6 +300,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
 
   // ---- leaf pass: the slots popped from Q_LEAF stand at a leaf ----
   auto leaf_pass = [&](int slot) {
+    const LaunchArgs& a = fresh_args();                 // this pass's own view of the arguments
+    SceneView scl = a.scene; scl.shadowNearest = NEAR ? 1 : 0;
+    const SceneView& sc = scl;
     const bool have = slot >= 0;
     if (CNT) { leafPasses++; leafLanes += (uint32_t)__popcll(__ballot(have)); }
     pendSlot = slot; pendDest = DEST_NONE;
@@ -346,6 +359,9 @@ __global__ void __launch_bounds__(kBlockThreads, kWavesPerSimd) pt_queuekernel(c
 
   // ---- shading / regeneration batch: run the path state machine for the popped slots ----
   auto run_batch = [&](int slot, bool shadeBatch) {
+    const LaunchArgs& a = fresh_args();                 // this pass's own view of the arguments
+    SceneView scl = a.scene; scl.shadowNearest = NEAR ? 1 : 0;
+    const SceneView& sc = scl;
     const bool have = slot >= 0;
     if (CNT) { batches++; batchLanes += (uint32_t)__popcll(__ballot(have)); }
     PT_SUB0();

@@ -88,7 +88,8 @@ def test_queue_and_drain_kernel_resources_are_pinned():
     queue = {k: v for k, v in res.items() if "pt_queuekernelILb0E" in k}        # the uncounted instantiations
     assert len(queue) >= 4, sorted(res)[:5]
     for k, v in queue.items():
-        assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= 40 and v["sgpr_spill_count"] <= 120, (k, v)
+        # round 6: 24-26 vector / 59 scalar once the passes take their own view of the arguments (fresh_args, as in the packet kernel); round 5: 31-40 / 118-120
+        assert v["vgpr_count"] <= 128 and v["vgpr_spill_count"] <= 26 and v["sgpr_spill_count"] <= 59, (k, v)
     drain = {k: v for k, v in res.items() if "pt_drainkernelILb0E" in k}
     assert len(drain) == 8, sorted(res)[:5]
     for k, v in drain.items():
