@@ -435,6 +435,33 @@ class GpuFrame:
             return None
         return "non-blocking (ncclCommInitRankConfig, calls polled against comm_timeout_ms)" if self.ctx.get_option("comm_nonblocking_used") else "blocking (ncclCommInitRank)"
 
+    def verify_frame(self):
+        """N > 1, rank 0, outside the timed region: the frame the ranks just rendered and collected against rank 0's OWN render of the whole frame
+        (a second context, one rank, same seeds).  The tile split must give the same bits -- every pixel's samples are the same work wherever
+        they run, and the gather only moves them --, the sample split the same sums within dist.SAMPLE_SPLIT_TOL.  The first run on a real
+        multi-GPU node thereby checks the data path through RCCL, not only times it."""
+        if self.world <= 1 or self.rank != 0:
+            return None
+        torch, a = self.torch, self.a
+        self.flush(); self.sync()
+        got = self.accums[0].clone()
+        ctx1 = self.M.Context(self.local)
+        try:
+            ctx1.load(self.hs)
+            ref = torch.zeros_like(got)
+            ctx1.accum_bind(ref.data_ptr())
+            ctx1.render(self.M.launch_seeds(a.spp))
+            torch.cuda.synchronize()
+            if self.sample_split:
+                err = float((got - ref).abs().max().item()) / max(1, a.spp)
+                ok = err <= self.D.SAMPLE_SPLIT_TOL
+                return {"what": "sample split + reduce against rank 0's own one-GPU render of the frame", "ok": bool(ok), "max_abs_diff_per_sample": err, "bound": self.D.SAMPLE_SPLIT_TOL}
+            same = bool(torch.equal(got.view(torch.int32), ref.view(torch.int32)))
+            return {"what": "tile split + gather against rank 0's own one-GPU render of the frame", "ok": same, "bit_identical": same,
+                    "pixels_differing": 0 if same else int((got.view(-1, 3) != ref.view(-1, 3)).any(dim=1).sum().item())}
+        finally:
+            ctx1.close()
+
     def first_frame(self):
         """A context's FIRST frame: no depth history orders its work yet, so the launch ends with the deepest paths walking alone
         (csrc/drainkernel.hip takes them over).  Trace-kernel ms of one frame rendered like that (HIP events on the launch stream: the
@@ -674,6 +701,7 @@ def run_rank(a, frame_cls=GpuFrame):
     # ---- the timed region, once per mode: W untimed frames, then exactly K frames between barrier + synchronize, MAX over ranks ----
     modes = fr.modes() if hasattr(fr, "modes") else ["one_frame"]
     results = {}
+    frame_check = None
     for mi, mode in enumerate(modes):
         failed = None
         try:
@@ -729,6 +757,11 @@ def run_rank(a, frame_cls=GpuFrame):
             dist.all_gather(per_rank, mine)
         per_rank = [[float(x) for x in t.tolist()] for t in per_rank]
         results[mode] = {"ms_per_step": dt / a.steps * 1e3, "dt": dt, "kms": kms, "nlaunch": nlaunch, "reduce_ms": reduce_ms, "per_rank": per_rank}
+        if mi == 0 and hasattr(fr, "verify_frame"):
+            try:
+                frame_check = fr.verify_frame()
+            except Exception as e:
+                frame_check = {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}
     good = {m: r for m, r in results.items() if "ms_per_step" in r}
     if not good:
         give_up("no mode could be timed", ["%s: %s" % (m, r.get("error")) for m, r in results.items()])
@@ -779,6 +812,8 @@ def run_rank(a, frame_cls=GpuFrame):
                             # which of the timed modes `value` is, and every mode that was timed (K steps each) or tried
                             "mode": mode, "pipeline": mode == "two_in_flight", "modes": {m: mode_summary(r) for m, r in results.items()},
                             "communicator": fr.comm_kind() if hasattr(fr, "comm_kind") else None, "communicator_note": comm_note,
+                            # N > 1: the collected frame against rank 0's own one-GPU render (GpuFrame.verify_frame): bit-identical for the tile split
+                            "frame_check": frame_check,
                             "ms_per_frame": round(ms_per_step, 3),
                             # a context's first frame (no depth history orders its work yet): trace-kernel ms, next to the timed frames' mean
                             "first_frame_kernel_ms": round(first_ms, 3) if first_ms is not None else None,

@@ -161,5 +161,7 @@ def test_bench_py_two_ranks_on_one_gpu(split, pipeline):
     assert len(r["kernel_ms_per_frame"]) == 2 and min(r["kernel_ms_per_frame"]) > 0 and r["comm_ranks_seen"] == 2
     assert len(r["collective_ms_per_frame"]) == 2 and max(r["collective_ms_per_frame"]) > 0
     assert len(r["rays_per_frame"]) == 2 and sum(r["rays_per_frame"]) == d["config"]["rays_per_frame"]
+    fc = d["config"]["frame_check"]             # rank 0 rendered the whole frame itself and compared
+    assert fc["ok"] and (fc["bit_identical"] if split == "tile" else fc["max_abs_diff_per_sample"] <= fc["bound"]), fc
     if split == "tile":                       # the rotating tile deal: the two shares within a few per cent of each other
         assert abs(r["rays_per_frame"][0] - r["rays_per_frame"][1]) < 0.1 * sum(r["rays_per_frame"])
